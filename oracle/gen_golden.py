@@ -1,0 +1,156 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference code (build container only).
+
+    python oracle/gen_golden.py            # needs /root/reference; writes tests/golden/
+
+The reference's missing third-party imports are satisfied by oracle/stubs (see its README).  Random draws made
+inside the reference (`torch.randn([B,1,1,1])`, `randn_like`, `torch.rand(B, T)`; model.py:182,188, utils.py:390)
+are replaced by recorded tensors so the oracle and the HIP engine can be fed the same noise.
+"""
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+from micro_diffusion.models import dit as ref_dit            # noqa: E402  (the reference)
+from micro_diffusion.models import model as ref_model        # noqa: E402
+from micro_diffusion.models import utils as ref_utils        # noqa: E402
+from oracle import microdit_ref as orc                       # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def ref_dit_from_cfg(cfg: orc.RefConfig):
+    kw = dict(cfg.__dict__)
+    kw["qkv_multipliers"] = list(kw["qkv_multipliers"])
+    kw["ffn_multipliers"] = list(kw["ffn_multipliers"])
+    return ref_dit.DiT(**kw)
+
+
+class FakeVAE(torch.nn.Module):
+    class _C:
+        scaling_factor = 0.13025
+    config = _C()
+
+
+def ref_latent_diffusion(dit, p_mean, p_std, mask_ratio):
+    return ref_model.LatentDiffusion(dit, FakeVAE(), torch.nn.Identity(), None, p_mean=p_mean, p_std=p_std,
+                                     train_mask_ratio=mask_ratio)
+
+
+class Recorded:
+    """Feeds recorded tensors to the reference's torch.randn / torch.rand calls, in call order."""
+
+    def __init__(self, randn_list, rand_list):
+        self.randn_list, self.rand_list = list(randn_list), list(rand_list)
+
+    def randn(self, *a, **k):
+        return self.randn_list.pop(0).clone()
+
+    def rand(self, *a, **k):
+        return self.rand_list.pop(0).clone()
+
+
+micro_config = orc.micro_config
+
+
+def gen_mask():
+    g = torch.Generator().manual_seed(7)
+    noise = torch.rand(6, 256, generator=g)
+    noise[1, 10] = noise[1, 200]            # injected exact ties
+    noise[2, 5] = noise[2, 6] = noise[2, 250]
+    noise[3, :] = 0.5                       # fully tied row
+    noise[4, ::2] = noise[4, 1::2]
+    out = {"noise": noise.numpy()}
+    for ratio in (0.75, 0.5):
+        rec = Recorded([], [noise])
+        with mock.patch.object(torch, "rand", rec.rand):
+            md = ref_utils.get_mask(6, 256, ratio, torch.device("cpu"))
+        out[f"ids_keep_{ratio}"] = md["ids_keep"].numpy()
+        out[f"ids_restore_{ratio}"] = md["ids_restore"].numpy()
+        out[f"mask_{ratio}"] = md["mask"].numpy()
+    np.savez_compressed(os.path.join(OUT, "mask.npz"), **out)
+    print("mask.npz")
+
+
+def gen_pos():
+    out = {}
+    for name, dim, grid, scale in (("a", 64, 8, 1.0), ("b", 64, 8, 2.0), ("c", 128, 4, 1.0)):
+        ref = ref_utils.get_2d_sincos_pos_embed(dim, grid, pos_interp_scale=scale, base_size=grid)
+        mine = orc.sincos_pos_embed(dim, grid, scale, grid)
+        assert np.array_equal(ref, mine), "oracle pos-embed restatement differs from the reference"
+        out[name] = ref.astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, "pos_embed.npz"), **out)
+    print("pos_embed.npz")
+
+
+def gen_model(tag, cfg, B, seed, mask_ratio, p_mean, p_std, cap_len):
+    sd = orc.synth_state_dict(cfg, seed)
+    dit = ref_dit_from_cfg(cfg)
+    ref_keys = {k: tuple(v.shape) for k, v in dit.state_dict().items()}
+    assert ref_keys == orc.state_shapes(cfg), "oracle state_shapes() differs from the reference state_dict"
+    dit.load_state_dict(sd)
+    assert np.array_equal(dit.pos_embed.numpy(), sd["pos_embed"].numpy())
+    model = ref_latent_diffusion(dit, p_mean, p_std, mask_ratio)
+    model.train()
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1, cap_len=cap_len)
+    rec = Recorded([rnd, epsn], [mnoise])
+    model.randn_like = lambda x: rec.randn()
+    bcopy = {k: v.clone() for k, v in batch.items()}
+    with mock.patch.object(torch, "randn", rec.randn), mock.patch.object(torch, "rand", rec.rand):
+        loss, _, _ = model(bcopy)
+    loss.backward()
+    grads = {k: p.grad for k, p in dit.named_parameters()}
+    # raw DiT forward (F_x) for the same preconditioned input, via the oracle's own precond (pure algebra)
+    sigma = (rnd * p_std + p_mean).exp()
+    c_in = 1 / (0.9 ** 2 + sigma ** 2).sqrt()
+    xin = c_in * (batch["image_latents"].float() + epsn * sigma)
+    cond = batch["caption_latents"].float() * batch["drop_caption_mask"].view(-1, 1, 1, 1)
+    rec2 = Recorded([], [mnoise])
+    with torch.no_grad(), mock.patch.object(torch, "rand", rec2.rand):
+        o = dit(xin, (sigma.log() / 4).flatten(), cond, mask_ratio=mask_ratio)
+    out = {"loss": np.float64(loss.item()), "sample": o["sample"].numpy(),
+           "mask": (o["mask"].numpy() if o["mask"] is not None else np.zeros(0)),
+           "grad_keys": np.array(sorted(grads)),
+           "grad_norms": np.array([grads[k].double().norm().item() for k in sorted(grads)]),
+           "grad_sums": np.array([grads[k].double().sum().item() for k in sorted(grads)])}
+    keep = ["final_layer.linear.weight", "x_embedder.proj.weight", "t_embedder.mlp.0.bias",
+            "blocks.0.adaLN_modulation.1.bias", "patch_mixer.1.mlp.gate.weight", "blocks.1.norm3.weight",
+            "y_emb_preprocess.norm1.weight", "patch_mixer.0.attn.qkv.weight"]
+    for k in keep:
+        if k in grads:
+            out["grad::" + k] = grads[k].numpy()
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"{tag}.npz loss={loss.item():.6f}")
+
+
+def gen_init():
+    """Checksums of the reference initialisation under torch.manual_seed(18) (dit.py:577-627)."""
+    out = {}
+    for tag, cfg in (("tiny", orc.tiny_config()), ("micro", micro_config())):
+        torch.manual_seed(18)
+        sd = ref_dit_from_cfg(cfg).state_dict()
+        keys = sorted(sd)
+        out[f"{tag}_keys"] = np.array(keys)
+        out[f"{tag}_sum"] = np.array([sd[k].double().sum().item() for k in keys])
+        out[f"{tag}_abs"] = np.array([sd[k].double().abs().sum().item() for k in keys])
+    np.savez_compressed(os.path.join(OUT, "init_seed18.npz"), **out)
+    print("init_seed18.npz")
+
+
+if __name__ == "__main__":
+    gen_mask()
+    gen_pos()
+    gen_model("tiny_mask75", orc.tiny_config(), 4, 11, 0.75, -0.6, 1.2, 77)
+    gen_model("tiny_mask0", orc.tiny_config(), 2, 12, 0.0, -0.6, 1.2, 77)
+    gen_model("micro_mask50", micro_config(), 3, 13, 0.5, 0.0, 0.6, 20)
+    gen_init()

@@ -1,0 +1,107 @@
+"""Pins oracle/microdit_ref.py (the CPU restatement) to golden vectors recorded from the UNMODIFIED reference
+(oracle/gen_golden.py).  fp32 vs fp32: tolerances are float round-off only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import microdit_ref as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_mask_bit_exact():
+    """Rows without exact ties must equal the reference bit for bit.  On rows WITH ties the reference's own
+    result depends on the platform's (unstable) argsort (utils.py:391 passes no `stable=`; its CPU quicksort
+    and GPU radix sort break ties differently), so there the contract is the stable lowest-index-first order
+    (= torch.argsort(stable=True)) plus agreement with the reference on everything a tie
+    cannot change: the sorted key sequence and the number of kept tokens."""
+    z = np.load(os.path.join(G, "mask.npz"))
+    noise = torch.from_numpy(z["noise"])
+    B, L = noise.shape
+    tied = [len(np.unique(z["noise"][r])) < L for r in range(B)]
+    assert tied == [False, True, True, True, True, False]
+    for ratio in (0.75, 0.5):
+        md = orc.get_mask(noise, ratio)
+        keep, restore, mask = md["ids_keep"].numpy(), md["ids_restore"].numpy(), md["mask"].numpy()
+        len_keep = int(L * (1 - ratio))
+        for r in range(B):
+            if not tied[r]:
+                assert np.array_equal(keep[r], z[f"ids_keep_{ratio}"][r])
+                assert np.array_equal(restore[r], z[f"ids_restore_{ratio}"][r])
+                assert np.array_equal(mask[r], z[f"mask_{ratio}"][r])
+            shuffle = np.argsort(restore[r], kind="stable")          # inverse permutation
+            assert np.array_equal(np.sort(shuffle), np.arange(L))
+            keys = z["noise"][r][shuffle]
+            assert np.all(np.diff(keys) >= 0)                          # sorted
+            same = np.diff(keys) == 0
+            assert np.all(np.diff(shuffle)[same] > 0)                  # ties: lowest index first
+            ref_shuffle = np.argsort(z[f"ids_restore_{ratio}"][r], kind="stable")
+            assert np.array_equal(keys, z["noise"][r][ref_shuffle])   # same sorted key sequence as the reference
+            assert np.array_equal(keep[r], shuffle[:len_keep])
+            assert mask[r].sum() == z[f"mask_{ratio}"][r].sum() == L - len_keep
+            assert np.array_equal(mask[r], (restore[r] >= len_keep).astype(np.float32))
+
+
+def test_pos_embed_exact():
+    z = np.load(os.path.join(G, "pos_embed.npz"))
+    for name, dim, grid, scale in (("a", 64, 8, 1.0), ("b", 64, 8, 2.0), ("c", 128, 4, 1.0)):
+        assert np.array_equal(orc.sincos_pos_embed(dim, grid, scale, grid), z[name])
+
+
+CASES = [("tiny_mask75", orc.tiny_config, 4, 11, 0.75, -0.6, 1.2, 77),
+         ("tiny_mask0", orc.tiny_config, 2, 12, 0.0, -0.6, 1.2, 77),
+         ("micro_mask50", orc.micro_config, 3, 13, 0.5, 0.0, 0.6, 20)]
+
+
+@pytest.mark.parametrize("tag,cfgf,B,seed,ratio,pm,ps,cap", CASES)
+def test_forward_loss_grads(tag, cfgf, B, seed, ratio, pm, ps, cap):
+    z = np.load(os.path.join(G, tag + ".npz"))
+    cfg = cfgf()
+    sd = {k: v.clone().requires_grad_(k not in ("pos_embed", "mask_token")) for k, v in orc.synth_state_dict(cfg, seed).items()}
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1, cap_len=cap)
+    loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, ratio, pm, ps)
+    assert abs(loss.item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
+    loss.backward()
+    keys = [str(k) for k in z["grad_keys"]]
+    assert keys == sorted(k for k in sd if k not in ("pos_embed", "mask_token"))
+    norms = np.array([sd[k].grad.double().norm().item() for k in keys])
+    assert np.allclose(norms, z["grad_norms"], rtol=2e-3, atol=1e-7), np.abs(norms - z["grad_norms"]).max()
+    for k in z.files:
+        if k.startswith("grad::"):
+            g = sd[k[6:]].grad.numpy()
+            ref = z[k]
+            assert np.abs(g - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+    # raw network output F_x
+    sigma = (rnd * ps + pm).exp()
+    xin = (batch["image_latents"].float() + epsn * sigma) / (0.9 ** 2 + sigma ** 2).sqrt()
+    cond = batch["caption_latents"].float() * batch["drop_caption_mask"].view(-1, 1, 1, 1)
+    with torch.no_grad():
+        sample, mask = orc.dit_forward(sd, cfg, xin, (sigma.log() / 4).flatten(), cond, ratio, mnoise)
+    assert np.abs(sample.numpy() - z["sample"]).max() <= 1e-4 * np.abs(z["sample"]).max()
+    if ratio > 0:
+        assert np.array_equal(mask.numpy(), z["mask"])
+
+
+def test_optimizer_restatements():
+    """clip_grad_norm / adamw_step restatements vs torch's own implementations (train.py:39-43,85-86)."""
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(300))
+    p2 = p.detach().clone()
+    opt = torch.optim.AdamW([p], lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
+    m, v = torch.zeros(300), torch.zeros(300)
+    for step in range(1, 6):
+        g = torch.randn(300)
+        p.grad = g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_([p], 0.25)
+        g2 = g.clone()
+        n = orc.clip_grad_norm([g2], 0.25)
+        assert abs(n - n_ref.item()) < 1e-4
+        assert torch.allclose(g2, p.grad, rtol=1e-5, atol=1e-8)
+        opt.step()
+        orc.adamw_step(p2, g2, m, v, step, 2.4e-4)
+        assert torch.allclose(p2, p.detach(), rtol=1e-5, atol=1e-7)
+    assert orc.lr_factor("cosine_with_warmup", 0, 2500, 250000, 0.33) == 0.0
+    assert abs(orc.lr_factor("cosine_with_warmup", 1250, 2500, 250000, 0.33) - 0.5) < 1e-12
+    assert abs(orc.lr_factor("cosine_with_warmup", 250000, 2500, 250000, 0.33) - 0.33) < 1e-12
