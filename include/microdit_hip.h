@@ -67,6 +67,138 @@ typedef struct md_gemm_args {
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------- LayerNorm */
+/* y = LN(act(x + pos[row % pos_rows])) * w;  out = y * (1 + scale[row / rows_per_sample]) + shift[...].
+ * w (f32 [C]), pos (f32 [pos_rows, C]), act, scale/shift (bf16 [samples, ldmod]) are all optional.
+ * Replaces nn.LayerNorm(bias=False) under low-precision LayerNorm (utils.py:71-78, train.py:81-84), modulate
+ * (utils.py:28-30), the `+ pos_embed` of dit.py:479 and the act->norm order of Mlp (utils.py:63-68). */
+typedef struct md_ln_args {
+    const void* x;     /* bf16 [rows, ldx] */
+    const void* w;     /* f32 [C] or NULL */
+    const void* shift; /* bf16 or NULL */
+    const void* scale; /* bf16 or NULL */
+    const void* pos;   /* f32 or NULL */
+    void* out;         /* bf16 [rows, ldo] (forward only) */
+    void* mean;        /* f32 [rows]: written by fwd (optional), read by bwd */
+    void* rstd;        /* f32 [rows] */
+    int64_t rows, C, ldx, ldo, ldmod, rows_per_sample, pos_rows;
+    float eps;
+    int32_t act; /* md_act applied to x before the norm */
+} md_ln_args;
+
+typedef struct md_ln_bwd_args {
+    const void* dz;  /* bf16 [rows, lddz]: grad of the (modulated) output */
+    void* dx;        /* bf16 [rows, lddx] or NULL */
+    void* dscale;    /* f32 [samples, ldg] (+= via atomics) or NULL */
+    void* dshift;    /* f32 [samples, ldg] (+=) or NULL */
+    void* dw;        /* f32 [C] (+=) or NULL */
+    int64_t lddz, lddx, ldg;
+    int64_t rows_per_block; /* rows of one sample handled by one workgroup (column-sum granularity) */
+    int32_t accumulate;     /* dx += instead of dx = */
+} md_ln_bwd_args;
+
+int md_ln_fwd(const md_ln_args* a, hipStream_t stream);
+int md_ln_bwd(const md_ln_args* a, const md_ln_bwd_args* b, hipStream_t stream);
+
+/* Non-parametric LayerNorm over columns [col0, col0 + width) of every row of buf, in place; rstd saved.
+ * (ln_q / ln_k over ALL heads concatenated: utils.py:113-114,122-125,175-176,183-186.) */
+int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, float* rstd_out, float eps,
+                hipStream_t stream);
+/* d: grad buffer (in place, dy -> dx); y: the normalised forward output. */
+int md_qkln_bwd(void* d, int64_t ldd, int64_t dcol0, const void* y, int64_t ldy, int64_t ycol0, int64_t rows,
+                int64_t width, const float* rstd, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- attention */
+/* softmax(scale * Q K^T) V per (batch, head), non-causal, no mask.  Row r of head h of batch b of X lives at
+ * X + b*sX + r*ldX + h*hd (bf16), so packed qkv / kv projection buffers are addressed in place.
+ * lse / delta: f32 [B, H, Sq].  Replaces F.scaled_dot_product_attention (utils.py:127-132,188-193) + backward. */
+typedef struct md_attn_args {
+    const void *q, *k, *v;
+    void* o;          /* fwd: output; bwd: the forward output (input) */
+    void* lse;        /* fwd: written; bwd: read */
+    const void* d_o;  /* bwd: grad of o */
+    void *dq, *dk, *dv;
+    void* delta;      /* bwd workspace f32 [B, H, Sq] */
+    int64_t B, H, Sq, Skv;
+    int64_t ldq, ldk, ldv, ldo, sq, sk, sv, so;
+    int64_t lddq, lddk, lddv, lddo, sdq, sdk, sdv, sdo;
+    float scale;
+    int32_t hd; /* 32 or 64 */
+} md_attn_args;
+
+int md_attn_fwd(const md_attn_args* a, hipStream_t stream);
+int md_attn_bwd(const md_attn_args* a, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- elementwise */
+/* a = silu(h12[:, :f]) * h12[:, f:]  (FeedForward, dit.py:88-89) and its backward (dh12 from da). */
+int md_swiglu_fwd(const void* h12, int64_t ldh, void* a, int64_t lda, int64_t M, int64_t f, hipStream_t stream);
+int md_swiglu_bwd(const void* da, int64_t ldda, const void* h12, int64_t ldh, void* dh12, int64_t lddh, int64_t M, int64_t f,
+                  hipStream_t stream);
+/* adaLN-Zero gate backward (dit.py:236,238): dbr = gate[b] * dx; dgate[b, :] += sum_t dx * br.  All [rows, C] dense. */
+int md_gate_bwd(const void* dx, const void* br, const void* gate, int64_t ldgate, void* dbr, float* dgate, int64_t lddg,
+                int64_t rows, int64_t C, int64_t rows_per_sample, int64_t rows_per_block, hipStream_t stream);
+int md_act_fwd(const void* x, void* y, int64_t n, int32_t act, hipStream_t stream);               /* bf16 -> bf16 */
+int md_act_bwd(const float* dy, const void* x, void* dx, int64_t n, int32_t act, hipStream_t stream); /* dx = dy*act'(x) */
+int md_colsum(const void* x, int32_t x_is_f32, int64_t ld, float* out, int64_t rows, int64_t C, hipStream_t stream); /* out += */
+int md_cast_f32_bf16(const float* x, void* y, int64_t n, const float* scale_ptr, hipStream_t stream);
+/* y(bf16)[r, :] = x[r, :] * rowscale[r / rows_per_sample]; x_dtype 0 = f16, 1 = f32 (caption cast + drop, model.py:132-139) */
+int md_cast_rows_bf16(const void* x, int32_t x_dtype, void* y, int64_t rows, int64_t C, const float* rowscale,
+                      int64_t rows_per_sample, hipStream_t stream);
+int md_mean_tokens(const void* y, void* out, int64_t B, int64_t L, int64_t C, hipStream_t stream);     /* dit.py:484 */
+int md_mean_tokens_bwd(const void* dpool, float* dy, int64_t B, int64_t L, int64_t C, hipStream_t stream); /* dy += */
+int md_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- masking / MoE routing */
+/* utils.py:382-403 given the uniform noise: stable ascending rank.  keep_rows[b*len_keep + r] = b*T + token with rank r
+ * (absolute row for md_gather_rows), ids_restore[b, t] = rank, mask[b, t] = rank >= len_keep. */
+int md_get_mask(const float* noise, int64_t B, int64_t T, int64_t len_keep, int32_t* keep_rows, int32_t* ids_restore,
+                float* mask, hipStream_t stream);
+int md_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* dst, int64_t ld_dst, int64_t n, int64_t C,
+                   hipStream_t stream);  /* dst[i] = src[idx[i]]   (mask_out_token utils.py:406-414; MoE dispatch) */
+int md_scatter_rows(const void* src, int64_t ld_src, const int32_t* idx, void* dst, int64_t ld_dst, int64_t n, int64_t C,
+                    hipStream_t stream); /* dst[idx[i]] = src[i]   (their backward; dst pre-zeroed) */
+/* Expert-choice routing (dit.py:131-133): probs = softmax(logits) (f32, rows padded to ld); expert e of sample n takes
+ * its k best tokens: rowidx/gval [E, B*k], slot [B*S, E] (position in the expert's list, or -1). */
+int md_moe_route(const float* logits, float* probs, int64_t ld, int64_t B, int64_t S, int32_t E, int32_t k, int32_t* rowidx,
+                 float* gval, int32_t* slot, hipStream_t stream);
+/* dit.py:141-142 + the gated residual of dit.py:238: br = sum_e g*h2, out = res + gate*br. */
+int md_moe_combine(const void* h2, const float* gval, const int32_t* slot, const void* res, const void* gate, int64_t ldgate,
+                   void* br, void* out, int64_t B, int64_t S, int32_t E, int32_t k, int64_t C, hipStream_t stream);
+int md_moe_combine_bwd(const void* dbr, const void* h2, const int32_t* rowidx, const float* gval, void* dh2, float* dgval,
+                       int64_t R, int64_t C, hipStream_t stream);
+int md_moe_dispatch_bwd(const void* dxin, const int32_t* slot, void* dx, const float* probs, int64_t ldp, const float* dgval,
+                        void* dlogits, int64_t ldo, int64_t B, int64_t S, int32_t E, int32_t k, int64_t C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- EDM front / back end */
+int md_edm_prepare(const float* x0, const float* eps, const float* rnd, float* xn, float* sigma, float* cin, float* cnoise,
+                   int64_t B, int64_t per_sample, float p_mean, float p_std, float sigma_data, hipStream_t stream);
+int md_patchify(const float* x, const float* scale, void* out, int64_t B, int32_t C, int32_t H, int32_t W, int32_t p,
+                hipStream_t stream);
+int md_timestep_embed(const float* t, void* out, int64_t B, int32_t dim, hipStream_t stream);
+int md_unpatchify(const void* tok, const int32_t* ids_restore, int64_t Tk, const float* mask_token, float* img, int64_t B,
+                  int32_t C, int32_t H, int32_t W, int32_t p, hipStream_t stream);
+/* model.py:177,199-210 on the kept tokens; dtok (optional) = d(batch-mean loss)/d(network output), f32 [B*Tk, C*p*p]. */
+int md_edm_loss(const void* tok, const int32_t* keep_rows, const float* xn, const float* x0, const float* sigma,
+                float* loss_per_sample, float* loss_mean, float* dtok, int64_t B, int64_t Tk, int32_t C, int32_t H, int32_t W,
+                int32_t p, float sigma_data, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- optimiser */
+int md_sumsq(const float* g, int64_t n, float* out, hipStream_t stream); /* out += sum g^2 */
+/* clip_grad_norm_ (train.py:85-86) + torch.optim.AdamW (train.py:39-43) + bf16 shadow emit, one pass. */
+typedef struct md_adamw_args {
+    void *p, *g, *m, *v; /* f32 [n] */
+    void* shadow;        /* bf16 [n] or NULL */
+    const void* sumsq;   /* f32 [1] device: sum of squared (unscaled) grads, or NULL for no clipping */
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm, grad_scale;
+    int32_t zero_grad;
+} md_adamw_args;
+int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- probes (tests only) */
+int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);
+int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,394 @@
+// Fused multi-head attention (forward + backward) for the four MicroDiT shapes: patch-mixer self-attention
+// (S = T), backbone self-attention over the un-masked tokens (S = Tk), cross-attention to the 77 caption tokens,
+// and the caption block's 77 x 77 self-attention.  Non-causal, no mask, head_dim 64 (XL/2) or 32 (Tiny).
+//
+// One wave owns 32 query rows (forward, dQ) or 32 key rows (dK/dV); K/V (resp. Q/dO) tiles of 32 rows are shared
+// by the workgroup's waves through LDS.  All products run on v_mfma_f32_32x32x16_bf16:
+//   S^T = K Q^T is computed "swapped" so that every lane holds one query column of the 32x32 score tile: the
+//   softmax max / sum are 16 in-register values + one cross-half shuffle (no LDS round trip), and the fp32
+//   probabilities are exactly the B operand of the following P.V product (O^T = V^T P^T) after a bf16 pack.
+//   Operands that are needed transposed (V^T, K^T, Q^T, dO^T) are read from the row-major LDS tile with
+//   ds_read_b64_tr_b16, so nothing is transposed through memory.
+// Replaces F.scaled_dot_product_attention (utils.py:127-132, 188-193) and its autograd backward.
+#include "md_common.h"
+#include "../../include/microdit_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x4 tr4(const unsigned char* p) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    U64 t;
+    t.s = v;
+    return t.h;
+}
+
+// A-operand fragment (32 rows x 16 k) of the TRANSPOSE of a row-major LDS tile T[k][col]:
+// result row = col0 + (lane & 31), k-slots 0..3 = T rows k_lo..k_lo+3, slots 4..7 = rows k_hi..k_hi+3.
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int pitch, int k_lo, int k_hi, int col0, int lane) {
+    const int li = lane & 15;
+    const int col = col0 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+    const bf16x4 lo = tr4(tile + (k_lo + (li >> 2)) * pitch + col * 2);
+    const bf16x4 hi = tr4(tile + (k_hi + (li >> 2)) * pitch + col * 2);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// Row-major fragment (row = row0 + (lane & 31), k = kbase + (lane >> 5) * 8 .. +7) from an LDS tile.
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int pitch, int kbase, int lane) {
+    U128 t;
+    t.u = *reinterpret_cast<const uint4*>(tile + (lane & 31) * pitch + (kbase + (lane >> 5) * 8) * 2);
+    return t.h;
+}
+
+// Stage 32 rows x HD of a [rows, ld] bf16 matrix (rows >= nrows are zero-filled) into an LDS tile.
+template <int HD>
+__device__ __forceinline__ void stage_tile(unsigned char* tile, int pitch, const bf16* src, int64_t ld, int64_t row0,
+                                           int64_t nrows, int tid, int nthreads) {
+    constexpr int CPR = HD / 8;
+    for (int task = tid; task < 32 * CPR; task += nthreads) {
+        const int r = task / CPR, c = task % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(tile + r * pitch + c * 16) = v;
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(a[base + e]);
+    return o;
+}
+
+// Store a transposed accumulator tile: acc[di] holds X^T[d][row] with lane <-> row, regs <-> d.
+template <int HD>
+__device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD / 32], float mul, int lane) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[di][4 * g + e] * mul);
+            st_bf16x4(dst_row + di * 32 + 8 * g + 4 * hh, o);
+        }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + 32 * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool qvalid = q < p.Sq;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+
+    bf16x8 qf[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (qvalid)
+            qf[s] = ld_bf16x8(Q + q * p.ldq + s * 16 + hh * 8);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = f2bf(0.f);
+    }
+    f32x16 oacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[di][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    for (int64_t key0 = 0; key0 < p.Skv; key0 += 32) {
+        __syncthreads();
+        stage_tile<HD>(sK, PK, K, p.ldk, key0, p.Skv, tid, nthreads);
+        stage_tile<HD>(sV, PK, V, p.ldv, key0, p.Skv, tid, nthreads);
+        __syncthreads();
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s)
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+        float tmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float v = key < p.Skv ? sacc[r] * p.scale : -1e30f;
+            sacc[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = __expf(sacc[r] - m_new);
+            sacc[r] = pr;
+            psum += pr;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[di][r] *= alpha;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 pf = pack8(sacc, 8 * sp);
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di)
+                oacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    tr_frag(sV, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, oacc[di], 0, 0, 0);
+        }
+    }
+    if (qvalid) {
+        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+        store_rows<HD>(O, oacc, 1.f / l, lane);
+        if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = m + __logf(l);
+    }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(md_attn_args p) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = p.B * p.H * p.Sq;
+    if (idx >= total) return;
+    const int64_t q = idx % p.Sq, h = (idx / p.Sq) % p.H, b = idx / (p.Sq * p.H);
+    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + q * p.ldo + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + q * p.lddo + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+        const bf16x8 a = ld_bf16x8(O + c * 8), d = ld_bf16x8(dO + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(d[e]);
+    }
+    reinterpret_cast<float*>(p.delta)[idx] = s;  // layout [B, H, Sq]: idx == (b*H + h)*Sq + q
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + 32 * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool qvalid = q < p.Sq;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+
+    bf16x8 qf[HD / 16], dof[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (qvalid) {
+            qf[s] = ld_bf16x8(Q + q * p.ldq + s * 16 + hh * 8);
+            dof[s] = ld_bf16x8(dO + q * p.lddo + s * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qf[s][e] = f2bf(0.f);
+                dof[s][e] = f2bf(0.f);
+            }
+        }
+    }
+    const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] : 0.f;
+    const float dlt = qvalid ? reinterpret_cast<const float*>(p.delta)[(b * p.H + h) * p.Sq + q] : 0.f;
+    f32x16 dqacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
+
+    for (int64_t key0 = 0; key0 < p.Skv; key0 += 32) {
+        __syncthreads();
+        stage_tile<HD>(sK, PK, K, p.ldk, key0, p.Skv, tid, nthreads);
+        stage_tile<HD>(sV, PK, V, p.ldv, key0, p.Skv, tid, nthreads);
+        __syncthreads();
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = 0.f;
+            dpacc[r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
+            sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 dsf = pack8(sacc, 8 * sp);
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di)
+                dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    tr_frag(sK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
+        }
+    }
+    if (qvalid) {
+        bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+        store_rows<HD>(dQ, dqacc, 1.f, lane);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK + 2 * 32 * 4];
+    unsigned char* sQ = smem;
+    unsigned char* sdO = smem + 32 * PK;
+    float* sLse = reinterpret_cast<float*>(smem + 2 * 32 * PK);
+    float* sDlt = sLse + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t key = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool kvalid = key < p.Skv;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
+    const float* DLT = reinterpret_cast<const float*>(p.delta) + (b * p.H + h) * p.Sq;
+
+    bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (kvalid) {
+            kf[s] = ld_bf16x8(K + key * p.ldk + s * 16 + hh * 8);
+            vf[s] = ld_bf16x8(V + key * p.ldv + s * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kf[s][e] = f2bf(0.f);
+                vf[s][e] = f2bf(0.f);
+            }
+        }
+    }
+    f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkacc[di][r] = 0.f;
+            dvacc[di][r] = 0.f;
+        }
+
+    for (int64_t q0 = 0; q0 < p.Sq; q0 += 32) {
+        __syncthreads();
+        stage_tile<HD>(sQ, PK, Q, p.ldq, q0, p.Sq, tid, nthreads);
+        stage_tile<HD>(sdO, PK, dO, p.lddo, q0, p.Sq, tid, nthreads);
+        if (tid < 32) {
+            const bool v = q0 + tid < p.Sq;
+            sLse[tid] = v ? LSE[q0 + tid] : 0.f;
+            sDlt[tid] = v ? DLT[q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = 0.f;
+            dpacc[r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float pr = (q0 + ql < p.Sq) ? __expf(sacc[r] * p.scale - sLse[ql]) : 0.f;
+            sacc[r] = pr;                                           // P
+            dpacc[r] = pr * (dpacc[r] - sDlt[ql]) * p.scale;        // dS
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 pf = pack8(sacc, 8 * sp);
+            const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di) {
+                dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    tr_frag(sdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
+                dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    tr_frag(sQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+            }
+        }
+    }
+    if (kvalid) {
+        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
+        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+        store_rows<HD>(dK, dkacc, 1.f, lane);
+        store_rows<HD>(dV, dvacc, 1.f, lane);
+    }
+}
+
+inline int waves_for(int64_t S) {
+    int64_t w = (S + 31) / 32;
+    return (int)(w > 4 ? 4 : (w < 1 ? 1 : w));
+}
+
+inline bool attn_ok(const md_attn_args* a) {
+    return a && a->q && a->k && a->v && a->o && a->B > 0 && a->H > 0 && a->Sq > 0 && a->Skv > 0 &&
+           (a->hd == 32 || a->hd == 64) && a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0 &&
+           a->sq % 8 == 0 && a->sk % 8 == 0 && a->sv % 8 == 0 && a->so % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
+    if (!attn_ok(a)) return MD_BAD_ARG;
+    const int nw = waves_for(a->Sq);
+    dim3 grid((unsigned)((a->Sq + 32 * nw - 1) / (32 * nw)), (unsigned)a->H, (unsigned)a->B);
+    if (a->hd == 64)
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64 * nw), 0, stream, *a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64 * nw), 0, stream, *a);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
+    if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
+    if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
+    const int64_t total = a->B * a->H * a->Sq;
+    const int nwq = waves_for(a->Sq), nwk = waves_for(a->Skv);
+    dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
+    dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);
+    if (a->hd == 64) {
+        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * nwk), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64 * nwq), 0, stream, *a);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64 * nwk), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64 * nwq), 0, stream, *a);
+    }
+    MD_LAUNCH_CHECK();
+    return 0;
+}

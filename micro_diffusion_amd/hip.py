@@ -127,7 +127,70 @@ def _sig(name, *argtypes):
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int32, c_float
 
+class LnArgs(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("shift", c_void_p), ("scale", c_void_p), ("pos", c_void_p),
+                ("out", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("rows", c_int64), ("C", c_int64), ("ldx", c_int64), ("ldo", c_int64), ("ldmod", c_int64),
+                ("rows_per_sample", c_int64), ("pos_rows", c_int64), ("eps", c_float), ("act", c_int32)]
+
+
+class LnBwdArgs(Structure):
+    _fields_ = [("dz", c_void_p), ("dx", c_void_p), ("dscale", c_void_p), ("dshift", c_void_p), ("dw", c_void_p),
+                ("lddz", c_int64), ("lddx", c_int64), ("ldg", c_int64), ("rows_per_block", c_int64),
+                ("accumulate", c_int32)]
+
+
+class AttnArgs(Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p), ("lse", c_void_p),
+                ("d_o", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p), ("delta", c_void_p),
+                ("B", c_int64), ("H", c_int64), ("Sq", c_int64), ("Skv", c_int64),
+                ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
+                ("sq", c_int64), ("sk", c_int64), ("sv", c_int64), ("so", c_int64),
+                ("lddq", c_int64), ("lddk", c_int64), ("lddv", c_int64), ("lddo", c_int64),
+                ("sdq", c_int64), ("sdk", c_int64), ("sdv", c_int64), ("sdo", c_int64),
+                ("scale", c_float), ("hd", c_int32)]
+
+
+class AdamWArgs(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow", c_void_p),
+                ("sumsq", c_void_p), ("n", c_int64),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+                ("bias_corr1", c_float), ("bias_corr2", c_float), ("max_norm", c_float), ("grad_scale", c_float),
+                ("zero_grad", c_int32)]
+
+
 _sig("md_gemm_bf16", POINTER(GemmArgs), P)
+_sig("md_ln_fwd", POINTER(LnArgs), P)
+_sig("md_ln_bwd", POINTER(LnArgs), POINTER(LnBwdArgs), P)
+_sig("md_qkln_fwd", P, I64, I64, I64, I64, P, F32, P)
+_sig("md_qkln_bwd", P, I64, I64, P, I64, I64, I64, I64, P, P)
+_sig("md_attn_fwd", POINTER(AttnArgs), P)
+_sig("md_attn_bwd", POINTER(AttnArgs), P)
+_sig("md_swiglu_fwd", P, I64, P, I64, I64, I64, P)
+_sig("md_swiglu_bwd", P, I64, P, I64, P, I64, I64, I64, P)
+_sig("md_gate_bwd", P, P, P, I64, P, P, I64, I64, I64, I64, I64, P)
+_sig("md_act_fwd", P, P, I64, I32, P)
+_sig("md_act_bwd", P, P, P, I64, I32, P)
+_sig("md_colsum", P, I32, I64, P, I64, I64, P)
+_sig("md_cast_f32_bf16", P, P, I64, P, P)
+_sig("md_cast_rows_bf16", P, I32, P, I64, I64, P, I64, P)
+_sig("md_mean_tokens", P, P, I64, I64, I64, P)
+_sig("md_mean_tokens_bwd", P, P, I64, I64, I64, P)
+_sig("md_add_bf16", P, P, P, I64, P)
+_sig("md_get_mask", P, I64, I64, I64, P, P, P, P)
+_sig("md_gather_rows", P, I64, P, P, I64, I64, I64, P)
+_sig("md_scatter_rows", P, I64, P, P, I64, I64, I64, P)
+_sig("md_moe_route", P, P, I64, I64, I64, I32, I32, P, P, P, P)
+_sig("md_moe_combine", P, P, P, P, P, I64, P, P, I64, I64, I32, I32, I64, P)
+_sig("md_moe_combine_bwd", P, P, P, P, P, P, I64, I64, P)
+_sig("md_moe_dispatch_bwd", P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I64, P)
+_sig("md_edm_prepare", P, P, P, P, P, P, P, I64, I64, F32, F32, F32, P)
+_sig("md_patchify", P, P, P, I64, I32, I32, I32, I32, P)
+_sig("md_timestep_embed", P, P, I64, I32, P)
+_sig("md_unpatchify", P, P, I64, P, P, I64, I32, I32, I32, I32, P)
+_sig("md_edm_loss", P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I32, F32, P)
+_sig("md_sumsq", P, I64, P, P)
+_sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_debug_tr_probe", P, P, P)
 _sig("md_debug_mfma_probe", P, P, P, P)
 

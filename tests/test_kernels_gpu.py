@@ -1,0 +1,442 @@
+"""Kernel-level parity on the GPU: every HIP kernel family against a plain PyTorch fp32 reference of the same op
+(same bf16-rounded inputs).  Tolerances are bf16 output rounding (2^-8 relative) unless noted; index outputs are
+compared bit-exact."""
+from ctypes import byref
+
+import math
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close(a, b, rel=2e-2, abs_=1e-3, what=""):
+    a, b = a.detach().float(), b.detach().float()
+    err = (a - b).abs().max().item()
+    lim = rel * b.abs().max().item() + abs_
+    assert err <= lim, f"{what}: max err {err:.4g} > {lim:.4g} (ref max {b.abs().max().item():.4g})"
+
+
+def rel_rms(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("C,rows,rps", [(768, 512, 64), (1024, 154, 77), (256, 64, 16), (128, 96, 32), (2048, 32, 8)])
+@pytest.mark.parametrize("mod,act,pos", [(True, 0, False), (False, 0, False), (False, 1, False), (False, 0, True)])
+def test_ln_fwd_bwd(hip, C, rows, rps, mod, act, pos):
+    torch.manual_seed(C + rows + mod)
+    L = hip.lib()
+    st = hip.stream_ptr()
+    B = rows // rps
+    x = bf(torch.randn(rows, C, device=DEV) * 1.5 + 0.3)
+    w = (1 + 0.2 * torch.randn(C, device=DEV)).float()
+    shift = bf(torch.randn(B, 3 * C, device=DEV) * 0.3)
+    scale = bf(torch.randn(B, 3 * C, device=DEV) * 0.3)
+    posv = torch.randn(rps, C, device=DEV) if pos else None
+    out = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    a = hip.LnArgs(x.data_ptr(), w.data_ptr(), shift[:, C:].data_ptr() if mod else None,
+                   scale[:, 2 * C:].data_ptr() if mod else None, posv.data_ptr() if pos else None, out.data_ptr(),
+                   mean.data_ptr(), rstd.data_ptr(), rows, C, C, C, 3 * C, rps, rps if pos else 0, 1e-6, act)
+    hip.check(L.md_ln_fwd(byref(a), st), "ln_fwd")
+    # reference
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    shr = shift[:, C:2 * C].float().requires_grad_(True)
+    scr = scale[:, 2 * C:].float().requires_grad_(True)
+    xin = xr
+    if pos:
+        xin = xin + posv.repeat(B, 1)
+    if act:
+        xin = F.gelu(xin, approximate="tanh")
+    y = F.layer_norm(xin, (C,), wr, None, 1e-6)
+    if mod:
+        y = y * (1 + scr.repeat_interleave(rps, 0)) + shr.repeat_interleave(rps, 0)
+    torch.cuda.synchronize()
+    close(out, y, what="ln fwd")
+    # backward
+    dz = bf(torch.randn(rows, C, device=DEV))
+    y.backward(dz.float())
+    dx = bf(torch.randn(rows, C, device=DEV))
+    dx0 = dx.clone()
+    dmod = torch.zeros(B, 6 * C, device=DEV)
+    dw = torch.zeros(C, device=DEV)
+    b = hip.LnBwdArgs(dz.data_ptr(), dx.data_ptr(), dmod[:, C:].data_ptr() if mod else None,
+                      dmod[:, 0:].data_ptr() if mod else None, dw.data_ptr(), C, C, 6 * C, 16, 1)
+    hip.check(L.md_ln_bwd(byref(a), byref(b), st), "ln_bwd")
+    torch.cuda.synchronize()
+    close(dx.float() - dx0.float(), xr.grad, rel=3e-2, what="ln dx")
+    close(dw, wr.grad, rel=2e-2, what="ln dw")
+    if mod:
+        close(dmod[:, C:2 * C], scr.grad, rel=2e-2, what="dscale")
+        close(dmod[:, :C], shr.grad, rel=2e-2, what="dshift")
+
+
+@pytest.mark.parametrize("width", [512, 768, 1024, 128])
+def test_qkln(hip, width):
+    torch.manual_seed(width)
+    L, st = hip.lib(), hip.stream_ptr()
+    rows, ld = 200, 3 * width
+    buf = bf(torch.randn(rows, ld, device=DEV) * 2 + 0.5)
+    ref_in = buf.float().clone().requires_grad_(True)
+    rstd = torch.empty(2, rows, device=DEV)
+    work = buf.clone()
+    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, 0, width, rstd[0].data_ptr(), 1e-6, st), "qkln q")
+    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, width, width, rstd[1].data_ptr(), 1e-6, st), "qkln k")
+    q = F.layer_norm(ref_in[:, :width], (width,), None, None, 1e-6)
+    k = F.layer_norm(ref_in[:, width:2 * width], (width,), None, None, 1e-6)
+    torch.cuda.synchronize()
+    close(work[:, :width], q, what="qkln q")
+    close(work[:, width:2 * width], k, what="qkln k")
+    assert torch.equal(work[:, 2 * width:], buf[:, 2 * width:])
+    d = bf(torch.randn(rows, ld, device=DEV))
+    (q * d[:, :width].float()).sum().backward(retain_graph=True)
+    (k * d[:, width:2 * width].float()).sum().backward()
+    dwork = d.clone()
+    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, 0, work.data_ptr(), ld, 0, rows, width, rstd[0].data_ptr(), st), "b")
+    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, width, work.data_ptr(), ld, width, rows, width, rstd[1].data_ptr(), st), "b")
+    torch.cuda.synchronize()
+    close(dwork[:, :2 * width], ref_in.grad[:, :2 * width], rel=3e-2, what="qkln bwd")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, H, hd):
+    B, Sq, _ = q.shape
+    qh = q.view(B, Sq, H, hd).transpose(1, 2)
+    kh = k.view(B, -1, H, hd).transpose(1, 2)
+    vh = v.view(B, -1, H, hd).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1)
+    return (att @ vh).transpose(1, 2).reshape(B, Sq, H * hd)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,hd,packed", [(3, 4, 64, 64, 64, True), (2, 12, 256, 256, 64, True),
+                                                    (2, 16, 64, 77, 64, False), (2, 3, 77, 77, 64, True),
+                                                    (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
+                                                    (1, 2, 1024, 1024, 64, True)])
+def test_attention(hip, B, H, Sq, Skv, hd, packed):
+    torch.manual_seed(B * H + Sq + Skv + hd)
+    L, st = hip.lib(), hip.stream_ptr()
+    hid = H * hd
+    if packed:   # self-attention: [B, S, 3, H, hd]
+        qkv = bf(torch.randn(B, Sq, 3 * hid, device=DEV))
+        q, k, v = qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:]
+        ldq = ldk = ldv = 3 * hid
+        sq = sk = sv = Sq * 3 * hid
+        dqkv = torch.zeros_like(qkv)
+        dq, dk, dv = dqkv[..., :hid], dqkv[..., hid:2 * hid], dqkv[..., 2 * hid:]
+        lddq = lddk = lddv = 3 * hid
+        sdq = sdk = sdv = Sq * 3 * hid
+    else:        # cross-attention: q [B,Sq,hid], kv [B,Skv,2,H,hd]
+        qb = bf(torch.randn(B, Sq, hid, device=DEV))
+        kv = bf(torch.randn(B, Skv, 2 * hid, device=DEV))
+        q, k, v = qb, kv[..., :hid], kv[..., hid:]
+        ldq, ldk, ldv = hid, 2 * hid, 2 * hid
+        sq, sk, sv = Sq * hid, Skv * 2 * hid, Skv * 2 * hid
+        dqb = torch.zeros_like(qb)
+        dkv = torch.zeros_like(kv)
+        dq, dk, dv = dqb, dkv[..., :hid], dkv[..., hid:]
+        lddq, lddk, lddv = hid, 2 * hid, 2 * hid
+        sdq, sdk, sdv = Sq * hid, Skv * 2 * hid, Skv * 2 * hid
+    o = torch.zeros(B, Sq, hid, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, Sq, device=DEV)
+    delta = torch.zeros(B, H, Sq, device=DEV)
+    do = bf(torch.randn(B, Sq, hid, device=DEV))
+    a = hip.AttnArgs(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(),
+                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Sq, Skv,
+                     ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
+                     1.0 / math.sqrt(hd), hd)
+    hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
+    hip.check(L.md_attn_bwd(byref(a), st), "attn bwd")
+    qr = q.float().clone().requires_grad_(True)
+    kr = k.float().clone().requires_grad_(True)
+    vr = v.float().clone().requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, H, hd)
+    ref.backward(do.float())
+    torch.cuda.synchronize()
+    assert rel_rms(o, ref) < 1e-2, rel_rms(o, ref)
+    close(o, ref, rel=3e-2, what="attn out")
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        r = rel_rms(got, want)
+        assert r < 2e-2, f"{name} rel-rms {r}"
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_swiglu_gate_act_colsum(hip):
+    torch.manual_seed(1)
+    L, st = hip.lib(), hip.stream_ptr()
+    M, f = 300, 512
+    h12 = bf(torch.randn(M, 2 * f, device=DEV))
+    a = torch.empty(M, f, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_swiglu_fwd(h12.data_ptr(), 2 * f, a.data_ptr(), f, M, f, st), "swiglu")
+    hr = h12.float().requires_grad_(True)
+    ar = F.silu(hr[:, :f]) * hr[:, f:]
+    da = bf(torch.randn(M, f, device=DEV))
+    ar.backward(da.float())
+    dh = torch.empty_like(h12)
+    hip.check(L.md_swiglu_bwd(da.data_ptr(), f, h12.data_ptr(), 2 * f, dh.data_ptr(), 2 * f, M, f, st), "swiglu bwd")
+    torch.cuda.synchronize()
+    close(a, ar, what="swiglu")
+    close(dh, hr.grad, what="swiglu bwd")
+    # gate backward
+    rows, C, rps = 384, 768, 64
+    B = rows // rps
+    dx, br = bf(torch.randn(rows, C, device=DEV)), bf(torch.randn(rows, C, device=DEV))
+    mod = bf(torch.randn(B, 6 * C, device=DEV))
+    dbr = torch.empty_like(dx)
+    dmod = torch.zeros(B, 6 * C, device=DEV)
+    hip.check(L.md_gate_bwd(dx.data_ptr(), br.data_ptr(), mod[:, 2 * C:].data_ptr(), 6 * C, dbr.data_ptr(),
+                            dmod[:, 2 * C:].data_ptr(), 6 * C, rows, C, rps, 32, st), "gate bwd")
+    torch.cuda.synchronize()
+    g = mod[:, 2 * C:3 * C].float().repeat_interleave(rps, 0)
+    close(dbr, g * dx.float(), what="dbr")
+    close(dmod[:, 2 * C:3 * C], (dx.float() * br.float()).view(B, rps, C).sum(1), what="dgate")
+    assert dmod[:, :2 * C].abs().max() == 0 and dmod[:, 3 * C:].abs().max() == 0
+    # act fwd / bwd
+    x = bf(torch.randn(256, 1024, device=DEV))
+    y = torch.empty_like(x)
+    hip.check(L.md_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), hip.ACT_GELU_TANH, st), "act")
+    xr = x.float().requires_grad_(True)
+    yr = F.gelu(xr, approximate="tanh")
+    dy = torch.randn(256, 1024, device=DEV)
+    yr.backward(dy)
+    dxo = torch.empty_like(x)
+    hip.check(L.md_act_bwd(dy.data_ptr(), x.data_ptr(), dxo.data_ptr(), x.numel(), hip.ACT_GELU_TANH, st), "act bwd")
+    torch.cuda.synchronize()
+    close(y, yr, what="gelu")
+    close(dxo, xr.grad, what="gelu bwd")
+    # colsum (bf16 and f32), accumulating
+    xs = bf(torch.randn(1000, 520, device=DEV))
+    out = torch.ones(520, device=DEV)
+    hip.check(L.md_colsum(xs.data_ptr(), 0, 520, out.data_ptr(), 1000, 520, st), "colsum")
+    xf = torch.randn(300, 48, device=DEV)
+    out2 = torch.zeros(48, device=DEV)
+    hip.check(L.md_colsum(xf.data_ptr(), 1, 48, out2.data_ptr(), 300, 48, st), "colsum f32")
+    torch.cuda.synchronize()
+    close(out, 1 + xs.float().sum(0), rel=1e-3, what="colsum")
+    close(out2, xf.sum(0), rel=1e-4, what="colsum f32")
+    # casts, mean tokens
+    Bc, Lc, Cc = 5, 77, 256
+    cap = torch.randn(Bc, Lc, Cc, device=DEV).half()
+    drop = torch.tensor([1., 0., 1., 1., 0.], device=DEV)
+    yb = torch.empty(Bc * Lc, Cc, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_cast_rows_bf16(cap.data_ptr(), 0, yb.data_ptr(), Bc * Lc, Cc, drop.data_ptr(), Lc, st), "cast rows")
+    pooled = torch.empty(Bc, Cc, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_mean_tokens(yb.data_ptr(), pooled.data_ptr(), Bc, Lc, Cc, st), "mean")
+    dyf = torch.ones(Bc * Lc, Cc, device=DEV)
+    hip.check(L.md_mean_tokens_bwd(pooled.data_ptr(), dyf.data_ptr(), Bc, Lc, Cc, st), "mean bwd")
+    torch.cuda.synchronize()
+    capr = cap.float() * drop.view(-1, 1, 1)
+    close(yb.view(Bc, Lc, Cc), capr, what="cast rows")
+    close(pooled, yb.float().view(Bc, Lc, Cc).mean(1), what="mean tokens")
+    close(dyf.view(Bc, Lc, Cc), 1 + pooled.float().unsqueeze(1) / Lc, rel=1e-3, what="mean bwd")
+
+
+# ------------------------------------------------------------------------------------------------ masking / routing
+@pytest.mark.parametrize("T,ratio", [(256, 0.75), (1024, 0.75), (64, 0.5)])
+def test_get_mask_bit_exact(hip, T, ratio):
+    torch.manual_seed(T)
+    L, st = hip.lib(), hip.stream_ptr()
+    B = 9
+    noise = torch.rand(B, T, device=DEV)
+    noise[1, 3] = noise[1, T - 1]
+    noise[2, :] = 0.25
+    noise[3, ::2] = noise[3, 1::2]
+    len_keep = int(T * (1 - ratio))
+    keep = torch.empty(B * len_keep, dtype=torch.int32, device=DEV)
+    restore = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    mask = torch.empty(B, T, device=DEV)
+    hip.check(L.md_get_mask(noise.data_ptr(), B, T, len_keep, keep.data_ptr(), restore.data_ptr(), mask.data_ptr(), st), "mask")
+    torch.cuda.synchronize()
+    n = noise.cpu()
+    shuffle = torch.argsort(n, dim=1, stable=True)
+    r = torch.argsort(shuffle, dim=1, stable=True)
+    assert torch.equal(restore.cpu().long(), r)
+    assert torch.equal(keep.cpu().long().view(B, len_keep), shuffle[:, :len_keep] + torch.arange(B).view(-1, 1) * T)
+    assert torch.equal(mask.cpu(), (r >= len_keep).float())
+    # gather / scatter round trip
+    C = 128
+    x = bf(torch.randn(B * T, C, device=DEV))
+    g = torch.empty(B * len_keep, C, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_gather_rows(x.data_ptr(), C, keep.data_ptr(), g.data_ptr(), C, B * len_keep, C, st), "gather")
+    back = torch.zeros_like(x)
+    hip.check(L.md_scatter_rows(g.data_ptr(), C, keep.data_ptr(), back.data_ptr(), C, B * len_keep, C, st), "scatter")
+    torch.cuda.synchronize()
+    assert torch.equal(g, x[keep.long()])
+    m = mask.view(-1, 1).bool()
+    assert torch.equal(back, torch.where(m, torch.zeros_like(x), x))
+
+
+@pytest.mark.parametrize("B,S,E,d", [(4, 64, 8, 256), (3, 256, 8, 128), (2, 64, 4, 128)])
+def test_moe_routing_combine(hip, B, S, E, d):
+    torch.manual_seed(S + E)
+    L, st = hip.lib(), hip.stream_ptr()
+    k = int(2.0 * S / E)
+    ld = 8
+    M, Bk = B * S, B * k
+    logits = torch.zeros(M, ld, device=DEV)
+    logits[:, :E] = bf(torch.randn(M, E, device=DEV)).float()
+    probs = torch.empty(M, ld, device=DEV)
+    rowidx = torch.empty(E, Bk, dtype=torch.int32, device=DEV)
+    gval = torch.empty(E, Bk, device=DEV)
+    slot = torch.empty(M, E, dtype=torch.int32, device=DEV)
+    hip.check(L.md_moe_route(logits.data_ptr(), probs.data_ptr(), ld, B, S, E, k, rowidx.data_ptr(), gval.data_ptr(),
+                             slot.data_ptr(), st), "route")
+    torch.cuda.synchronize()
+    pr = torch.softmax(logits[:, :E], -1).view(B, S, E).requires_grad_(True)
+    g, m = torch.topk(pr.permute(0, 2, 1), k, dim=-1)       # [B,E,k]
+    close(probs[:, :E], pr.reshape(M, E), rel=1e-5, what="probs")
+    # same SETS (ordering inside top-k for exact ties may differ; values are tie-free here) and same order
+    got_idx = rowidx.view(E, B, k).permute(1, 0, 2).cpu().long() - (torch.arange(B) * S).view(B, 1, 1)
+    assert torch.equal(got_idx, m.cpu())
+    close(gval.view(E, B, k).permute(1, 0, 2), g, rel=1e-5, what="gval")
+    # combine forward
+    h2 = bf(torch.randn(E, Bk, d, device=DEV))
+    res = bf(torch.randn(M, d, device=DEV))
+    mod = bf(torch.randn(B, 6 * d, device=DEV))
+    br = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    out = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_moe_combine(h2.data_ptr(), gval.data_ptr(), slot.data_ptr(), res.data_ptr(), mod[:, 5 * d:].data_ptr(),
+                               6 * d, br.data_ptr(), out.data_ptr(), B, S, E, k, d, st), "combine")
+    h2r = h2.float().view(E, B, k, d).permute(1, 0, 2, 3).clone().requires_grad_(True)   # [B,E,k,d]
+    comb = torch.zeros(B, S, d, device=DEV)
+    comb = comb.scatter_add(1, m.reshape(B, E * k, 1).expand(-1, -1, d), (g.unsqueeze(-1) * h2r).reshape(B, E * k, d))
+    torch.cuda.synchronize()
+    close(br, comb.view(M, d), rel=3e-2, what="combine br")
+    gate = mod[:, 5 * d:].float().repeat_interleave(S, 0)
+    close(out, res.float() + gate * br.float(), rel=2e-2, what="combine out")
+    # combine backward
+    dbr = bf(torch.randn(M, d, device=DEV))
+    comb.backward(dbr.float().view(B, S, d))
+    dh2 = torch.empty_like(h2)
+    dg = torch.empty(E, Bk, device=DEV)
+    hip.check(L.md_moe_combine_bwd(dbr.data_ptr(), h2.data_ptr(), rowidx.data_ptr(), gval.data_ptr(), dh2.data_ptr(),
+                                   dg.data_ptr(), E * Bk, d, st), "combine bwd")
+    torch.cuda.synchronize()
+    close(dh2.view(E, B, k, d).permute(1, 0, 2, 3), h2r.grad, rel=2e-2, what="dh2")
+    # dispatch backward + softmax backward
+    dxin = bf(torch.randn(E, Bk, d, device=DEV))
+    dx = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    dlog = torch.empty(M, ld, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_moe_dispatch_bwd(dxin.data_ptr(), slot.data_ptr(), dx.data_ptr(), probs.data_ptr(), ld, dg.data_ptr(),
+                                    dlog.data_ptr(), ld, B, S, E, k, d, st), "dispatch bwd")
+    torch.cuda.synchronize()
+    ref_dx = torch.zeros(B, S, d, device=DEV).scatter_add(
+        1, m.reshape(B, E * k, 1).expand(-1, -1, d), dxin.float().view(E, B, k, d).permute(1, 0, 2, 3).reshape(B, E * k, d))
+    close(dx, ref_dx.view(M, d), rel=2e-2, what="dispatch bwd")
+    # dlogits through softmax: compare against autograd of pr wrt logits
+    lg = logits[:, :E].clone().requires_grad_(True)
+    pr2 = torch.softmax(lg, -1).view(B, S, E)
+    g2, m2 = torch.topk(pr2.permute(0, 2, 1), k, dim=-1)
+    (g2 * dg.view(E, B, k).permute(1, 0, 2)).sum().backward()
+    close(dlog[:, :E], lg.grad, rel=3e-2, what="dlogits")
+    if E < ld:
+        assert dlog[:, E:].float().abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ EDM front/back end
+@pytest.mark.parametrize("masked", [True, False])
+def test_edm_patchify_loss(hip, masked):
+    torch.manual_seed(3)
+    L, st = hip.lib(), hip.stream_ptr()
+    B, C, H, W, p = 6, 4, 32, 32, 2
+    T = (H // p) * (W // p)
+    x0 = torch.randn(B, C, H, W, device=DEV) * 0.8
+    eps = torch.randn(B, C, H, W, device=DEV)
+    rnd = torch.randn(B, device=DEV)
+    xn, sigma, cin, cnoise = torch.empty_like(x0), torch.empty(B, device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    hip.check(L.md_edm_prepare(x0.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn.data_ptr(), sigma.data_ptr(), cin.data_ptr(),
+                               cnoise.data_ptr(), B, C * H * W, -0.6, 1.2, 0.9, st), "prepare")
+    patches = torch.empty(B * T, C * p * p, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_patchify(xn.data_ptr(), cin.data_ptr(), patches.data_ptr(), B, C, H, W, p, st), "patchify")
+    torch.cuda.synchronize()
+    s = (rnd * 1.2 - 0.6).exp()
+    close(sigma, s, rel=1e-5, what="sigma")
+    close(xn, x0 + eps * s.view(-1, 1, 1, 1), rel=1e-5, what="xn")
+    close(cnoise, s.log() / 4, rel=1e-4, what="cnoise")
+    c_in = 1 / (0.81 + s * s).sqrt()
+    ref_p = F.unfold(xn * c_in.view(-1, 1, 1, 1), p, stride=p).transpose(1, 2).reshape(B * T, C * p * p)
+    close(patches, ref_p, what="patchify")
+    # timestep embedding
+    te = torch.empty(B, 512, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_timestep_embed(cnoise.data_ptr(), te.data_ptr(), B, 512, st), "temb")
+    torch.cuda.synchronize()
+    fr = torch.exp(-math.log(10000) * torch.arange(256, device=DEV, dtype=torch.float32) / 256)
+    ar = cnoise[:, None] * fr[None]
+    close(te, torch.cat([ar.cos(), ar.sin()], -1), what="timestep emb")
+    # unpatchify + loss
+    Tk = T // 4 if masked else T
+    if masked:
+        noise = torch.rand(B, T, device=DEV)
+        keep = torch.empty(B * Tk, dtype=torch.int32, device=DEV)
+        restore = torch.empty(B, T, dtype=torch.int32, device=DEV)
+        mask = torch.empty(B, T, device=DEV)
+        hip.check(L.md_get_mask(noise.data_ptr(), B, T, Tk, keep.data_ptr(), restore.data_ptr(), mask.data_ptr(), st), "m")
+    tok = bf(torch.randn(B * Tk, C * p * p, device=DEV))
+    img = torch.empty(B, C, H, W, device=DEV)
+    hip.check(L.md_unpatchify(tok.data_ptr(), restore.data_ptr() if masked else None, Tk, None, img.data_ptr(), B, C, H, W, p,
+                              st), "unpatchify")
+    lps, lmean = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    dtok = torch.empty(B * Tk, C * p * p, device=DEV)
+    hip.check(L.md_edm_loss(tok.data_ptr(), keep.data_ptr() if masked else None, xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(),
+                            lps.data_ptr(), lmean.data_ptr(), dtok.data_ptr(), B, Tk, C, H, W, p, 0.9, st), "loss")
+    torch.cuda.synchronize()
+    tr = tok.float().clone().requires_grad_(True)
+    xt = tr.view(B, Tk, -1)
+    if masked:
+        xt = torch.cat([xt, torch.zeros(B, T - Tk, C * p * p, device=DEV)], 1)
+        xt = torch.gather(xt, 1, restore.long().unsqueeze(-1).expand(-1, -1, C * p * p))
+    g = H // p
+    Fx = xt.view(B, g, g, p, p, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W)
+    close(img, Fx, rel=1e-6, what="unpatchify")
+    sg = s.view(-1, 1, 1, 1)
+    D = 0.81 / (sg ** 2 + 0.81) * xn + sg * 0.9 / (sg ** 2 + 0.81).sqrt() * Fx
+    loss = (sg ** 2 + 0.81) / (sg * 0.9) ** 2 * (D - x0) ** 2
+    if masked:
+        lp = F.avg_pool2d(loss.mean(1), p).flatten(1)
+        um = 1 - mask
+        lp = (lp * um).sum(1) / um.sum(1)
+    else:
+        lp = loss.flatten(1).mean(1)
+    lp.mean().backward()
+    close(lps, lp, rel=1e-4, what="loss per sample")
+    close(lmean, lp.mean().view(1), rel=1e-4, what="loss mean")
+    close(dtok, tr.grad, rel=1e-3, what="dtok")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_adamw_clip(hip):
+    torch.manual_seed(4)
+    L, st = hip.lib(), hip.stream_ptr()
+    n = 4096 * 33
+    p = torch.randn(n, device=DEV)
+    pref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pref], lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    ss = torch.zeros(1, device=DEV)
+    for step in range(1, 5):
+        g = torch.randn(n, device=DEV) * (0.01 if step == 3 else 1.0)   # step 3: below the clip threshold
+        pref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pref], 0.25 if step != 3 else 1e9)
+        opt.step()
+        gw = g.clone()
+        ss.zero_()
+        hip.check(L.md_sumsq(gw.data_ptr(), n, ss.data_ptr(), st), "sumsq")
+        a = hip.AdamWArgs(p.data_ptr(), gw.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), ss.data_ptr(), n,
+                          2.4e-4, 0.9, 0.999, 1e-8, 0.1, 1 - 0.9 ** step, 1 - 0.999 ** step,
+                          0.25 if step != 3 else 1e9, 1.0, 1)
+        hip.check(L.md_adamw_step(byref(a), st), "adamw")
+        torch.cuda.synchronize()
+        assert abs(ss.item() - (g.double() ** 2).sum().item()) < 1e-3 * (g.double() ** 2).sum().item()
+        assert torch.allclose(p, pref.detach(), rtol=1e-5, atol=1e-6), (p - pref.detach()).abs().max()
+        assert gw.abs().max() == 0
+        assert torch.equal(shadow, p.to(torch.bfloat16))
