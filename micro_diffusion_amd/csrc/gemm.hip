@@ -297,11 +297,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
 extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if (!a || !a->A || !a->B || !a->C) return MD_BAD_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->ksplit <= 0) return MD_BAD_ARG;
-    // 16-byte chunk granularity: the contiguous dimension of every operand / output must be a multiple of 8.
-    if (a->N % 8) return MD_BAD_ARG;
-    if (a->a_kcontig ? (a->K % 8) : (a->M % 8)) return MD_BAD_ARG;
-    if (a->b_kcontig ? (a->K % 8) : (a->N % 8)) return MD_BAD_ARG;
-    if (a->lda % 8 || a->ldb % 8 || a->ldc % 4) return MD_BAD_ARG;
+    // All global accesses are 16-byte chunks of 8 bf16 along the contiguous dimension: leading dimensions must be
+    // multiples of 8 (4 for fp32 outputs).  A contiguous extent that is not a multiple of 8 (the MoE gate: N = K =
+    // num_experts) is allowed as long as the caller pads the rows to the next multiple of 8 with finite values
+    // (zeros): whole chunks are read / written whenever their first element is in range.
+    if (a->lda % 8 || a->ldb % 8) return MD_BAD_ARG;
+    if ((a->mode == MD_EPI_STORE_BF16 || a->mode == MD_EPI_RESIDUAL || a->mode == MD_EPI_DACT) ? (a->ldc % 8) : (a->ldc % 4))
+        return MD_BAD_ARG;
+    if (a->C2 && a->ldc2 % 8) return MD_BAD_ARG;
     if (a->ksplit > 1 && a->mode != MD_EPI_ATOMIC_F32) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;

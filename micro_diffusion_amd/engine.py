@@ -1,0 +1,642 @@
+"""DiTEngine — the hand-written forward AND backward of MicroDiT as an explicit sequence of HIP kernel launches.
+
+No autograd below this boundary: every backward op is launched by `backward()` in reverse order of `forward()`,
+reading the activations `forward()` saved in a `Tape`.  Host code is Python; every operation on device data is a
+call into libmicrodit_hip.so through ctypes (micro_diffusion_amd/hip.py).  PyTorch is used for device memory
+(`torch.empty`), the current HIP stream and nothing else.
+
+Reference being replaced (paths relative to /root/reference/micro_diffusion/models):
+  DiT.forward_without_cfg dit.py:455-519, DiTBlock.forward dit.py:232-239, FeedForward dit.py:88-89,
+  FeedForwardECMoe.forward dit.py:126-143, AttentionBlockPromptEmbedding dit.py:53-56, SelfAttention /
+  CrossAttention utils.py:116-136,178-197, T2IFinalLayer utils.py:236-240, TimestepEmbedder utils.py:283-285,
+  CaptionProjection/Mlp utils.py:63-68, get_mask / mask_out_token / unmask_tokens utils.py:382-426 — and the
+  autograd backward of all of them (no reference source: derived from the forward).
+
+Numerics contract (amp_bf16 + low-precision LayerNorm): bf16 storage for activations, weights
+(shadow copies of the fp32 masters) and activation gradients; fp32 accumulation in every GEMM / reduction; fp32
+LayerNorm statistics, softmax, MoE routing and weight gradients (accumulated into the fp32 `.grad` buffer).
+"""
+from __future__ import annotations
+
+import math
+from ctypes import byref
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip
+from .arch import BlockPlan, DiTConfig, caption_ffn_hidden, plan_blocks
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class Tape:
+    """Activations saved by one forward pass (plain attribute bag)."""
+    pass
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class DiTEngine:
+    def __init__(self, cfg: DiTConfig, params: Dict[str, torch.Tensor], shadows: Dict[str, torch.Tensor],
+                 grads: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor]):
+        """params: fp32 masters; shadows: bf16 copies (same names); grads: fp32 accumulators; buffers: pos_embed,
+        mask_token.  All are views into flat device buffers owned by the DiT module."""
+        self.cfg = cfg
+        self.P, self.S, self.G, self.buf = params, shadows, grads, buffers
+        self.mixer, self.backbone = plan_blocks(cfg)
+        self.dev = next(iter(params.values())).device
+        self.L = hip.lib()
+        self.wgrad_target_blocks = 768
+
+    # ------------------------------------------------------------------------------------------ launch helpers
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def empty(self, *shape, dtype=BF16):
+        return torch.empty(*shape, device=self.dev, dtype=dtype)
+
+    def zeros(self, *shape, dtype=F32):
+        return torch.zeros(*shape, device=self.dev, dtype=dtype)
+
+    def _gemm(self, **kw):
+        a = hip.GemmArgs()
+        for k, v in kw.items():
+            setattr(a, k, v)
+        hip.check(self.L.md_gemm_bf16(byref(a), self._st()), "md_gemm_bf16")
+
+    def lin_fwd(self, x, wname, out, M, N, K, *, ldx=None, ldc=None, mode=hip.EPI_STORE_BF16, act=0, res=None,
+                gate=None, ldg=0, rps=0, C2=None, ldc2=0, xoff=0, ooff=0, bias=True):
+        """out[M,N] = epilogue(x[M,K] @ W[N,K]^T + b).  x / out may be offset views (element offsets)."""
+        b = self.P.get(wname + ".bias") if bias else None
+        self._gemm(A=x.data_ptr() + 2 * xoff, B=self.S[wname + ".weight"].data_ptr(),
+                   C=out.data_ptr() + (4 if mode in (hip.EPI_STORE_F32, hip.EPI_ACCUM_F32) else 2) * ooff,
+                   C2=_p(C2), bias=_p(b), res=_p(res), gate=gate, M=M, N=N, K=K, lda=ldx or K, ldb=K, ldc=ldc or N,
+                   ldc2=ldc2 or N, ldr=N, ldg=ldg, rows_per_sample=rps, batch=1, ksplit=1, a_kcontig=1, b_kcontig=1,
+                   mode=mode, act=act, alpha=1.0)
+
+    def lin_dgrad(self, dy, wname, dx, M, N, K, *, lddy=None, mode=hip.EPI_STORE_BF16, act=0, aux=None, res=None,
+                  dyoff=0):
+        """dx[M,K] (=|+=) dy[M,N] @ W[N,K]   (contraction over N; W is the K-strided operand)."""
+        self._gemm(A=dy.data_ptr() + 2 * dyoff, B=self.S[wname + ".weight"].data_ptr(), C=dx.data_ptr(), aux=_p(aux),
+                   res=_p(res), M=M, N=K, K=N, lda=lddy or N, ldb=K, ldc=K, ldaux=K, ldr=K, batch=1, ksplit=1,
+                   a_kcontig=1, b_kcontig=0, mode=mode, act=act, alpha=1.0)
+
+    def _ksplit(self, out_rows, out_cols, contraction):
+        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+        ks = max(1, self.wgrad_target_blocks // tiles)
+        return max(1, min(ks, (contraction + 511) // 512))
+
+    def lin_wgrad(self, dy, x, wname, M, N, K, *, lddy=None, ldx=None, dyoff=0, xoff=0, bias_from=None):
+        """grad W[N,K] += dy[M,N]^T @ x[M,K]  (both operands K-strided, split-K atomics into the fp32 grad);
+        grad b[N] += column sums of dy."""
+        ks = self._ksplit(N, K, M)
+        self._gemm(A=dy.data_ptr() + 2 * dyoff, B=x.data_ptr() + 2 * xoff, C=self.G[wname + ".weight"].data_ptr(), M=N, N=K,
+                   K=M, lda=lddy or N, ldb=ldx or K, ldc=K, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
+                   mode=hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        gb = self.G.get(wname + ".bias")
+        if gb is not None:
+            src = dy if bias_from is None else bias_from
+            hip.check(self.L.md_colsum(src.data_ptr() + (0 if bias_from is not None else 2 * dyoff),
+                                       1 if src.dtype == F32 else 0, lddy or N, gb.data_ptr(), M, N, self._st()), "colsum")
+
+    def ln_args(self, x, wname, out, rows, C, *, shift=None, scale=None, ldmod=0, rps=0, mean=None, rstd=None, act=0,
+                pos=None, pos_rows=0):
+        return hip.LnArgs(x.data_ptr(), _p(self.P[wname + ".weight"]) if wname else None, shift, scale, _p(pos), _p(out),
+                          _p(mean), _p(rstd), rows, C, C, C, ldmod, rps, pos_rows, self.cfg.norm_eps, act)
+
+    def ln_fwd(self, a):
+        hip.check(self.L.md_ln_fwd(byref(a), self._st()), "md_ln_fwd")
+
+    def ln_bwd(self, a, dz, dx, *, accumulate, wname=None, dscale=None, dshift=None, ldg=0, rps_total=None):
+        rps = a.rows_per_sample if a.rows_per_sample > 0 else a.rows
+        rpb = 64 if rps >= 64 else int(rps)
+        b = hip.LnBwdArgs(dz.data_ptr(), _p(dx), dscale, dshift, _p(self.G[wname + ".weight"]) if wname else None,
+                          a.C, a.C, ldg, rpb, 1 if accumulate else 0)
+        hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd")
+
+    def attn_args(self, q, k, v, o, lse, B, H, Sq, Skv, ldq, ldk, ldv, hid, *, do=None, dq=None, dk=None, dv=None,
+                  delta=None, lddq=0, lddk=0, lddv=0):
+        hd = self.cfg.head_dim
+        return hip.AttnArgs(q, k, v, _p(o), _p(lse), _p(do), dq, dk, dv, _p(delta), B, H, Sq, Skv, ldq, ldk, ldv, hid,
+                            Sq * ldq, Skv * ldk, Skv * ldv, Sq * hid, lddq, lddk, lddv, hid, Sq * lddq, Skv * lddk,
+                            Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd)
+
+    # ------------------------------------------------------------------------------------------ attention layers
+    def _self_attn_fwd(self, pre, xin, B, S, dim, hid, heads, t):
+        """xin [B*S, dim] -> o [B*S, hid]; saves qkv (post-LN), rstd, lse on tape t."""
+        M, L, st = B * S, self.L, self._st()
+        qkv = self.empty(M, 3 * hid)
+        self.lin_fwd(xin, pre + ".qkv", qkv, M, 3 * hid, dim)
+        rq = self.empty(2, M, dtype=F32)
+        hip.check(L.md_qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq[0].data_ptr(), self.cfg.norm_eps, st), "qkln")
+        hip.check(L.md_qkln_fwd(qkv.data_ptr(), M, 3 * hid, hid, hid, rq[1].data_ptr(), self.cfg.norm_eps, st), "qkln")
+        o = self.empty(M, hid)
+        lse = self.empty(B, heads, S, dtype=F32)
+        a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
+                           3 * hid, 3 * hid, 3 * hid, hid)
+        hip.check(L.md_attn_fwd(byref(a), st), "md_attn_fwd")
+        t.qkv, t.rq, t.o, t.lse = qkv, rq, o, lse
+        return o
+
+    def _self_attn_bwd(self, pre, xin, do, B, S, dim, hid, heads, t):
+        """do [M, hid] -> returns d_xin [M, dim]; accumulates the qkv weight grad."""
+        M, L, st = B * S, self.L, self._st()
+        dqkv = self.empty(M, 3 * hid)
+        delta = self.empty(B, heads, S, dtype=F32)
+        qkv = t.qkv
+        a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, t.o, t.lse, B, heads, S, S,
+                           3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
+                           dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
+        hip.check(L.md_attn_bwd(byref(a), st), "md_attn_bwd")
+        hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq[0].data_ptr(), st), "qkln bwd")
+        hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, hid, qkv.data_ptr(), 3 * hid, hid, M, hid, t.rq[1].data_ptr(), st), "qkln bwd")
+        self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim)
+        dxin = self.empty(M, dim)
+        self.lin_dgrad(dqkv, pre + ".qkv", dxin, M, 3 * hid, dim)
+        return dxin
+
+    # ------------------------------------------------------------------------------------------ DiT block
+    def _block_fwd(self, bp: BlockPlan, x, ycond, B, S, Lc, gc):
+        L, st, cfg = self.L, self._st(), self.cfg
+        d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
+        M, Mc, D = B * S, B * Lc, cfg.dim
+        n = bp.name
+        t = Tape()
+        t.x = x
+        mod = self.empty(B, 6 * d)
+        self.lin_fwd(gc, n + ".adaLN_modulation.1", mod, B, 6 * d, D)
+        mp = mod.data_ptr()
+        t.mod = mod
+        # -- self attention: x1 = x + gate_msa * proj(attn(modulate(LN1(x))))
+        t.xm1 = self.empty(M, d)
+        t.st1 = self.empty(2, M, dtype=F32)
+        a1 = self.ln_args(x, n + ".norm1", t.xm1, M, d, shift=mp, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
+        self.ln_fwd(a1)
+        t.sa = Tape()
+        o = self._self_attn_fwd(n + ".attn", t.xm1, B, S, d, h, bp.heads, t.sa)
+        t.br1 = self.empty(M, d)
+        x1 = self.empty(M, d)
+        self.lin_fwd(o, n + ".attn.proj", x1, M, d, h, mode=hip.EPI_RESIDUAL, res=x, gate=mp + 2 * 2 * d, ldg=6 * d, rps=S,
+                     C2=t.br1)
+        t.x1 = x1
+        # -- cross attention: x2 = x1 + proj(attn(q(LN2(x1)), kv(y)))
+        t.xn2 = self.empty(M, d)
+        t.st2 = self.empty(2, M, dtype=F32)
+        self.ln_fwd(self.ln_args(x1, n + ".norm2", t.xn2, M, d, mean=t.st2[0], rstd=t.st2[1]))
+        t.q2 = self.empty(M, hx)
+        self.lin_fwd(t.xn2, n + ".cross_attn.q_linear", t.q2, M, hx, d)
+        t.kv = self.empty(Mc, 2 * hx)
+        self.lin_fwd(ycond, n + ".cross_attn.kv_linear", t.kv, Mc, 2 * hx, d)
+        t.rq2 = self.empty(M, dtype=F32)
+        t.rk2 = self.empty(Mc, dtype=F32)
+        hip.check(L.md_qkln_fwd(t.q2.data_ptr(), M, hx, 0, hx, t.rq2.data_ptr(), cfg.norm_eps, st), "qkln")
+        hip.check(L.md_qkln_fwd(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.rk2.data_ptr(), cfg.norm_eps, st), "qkln")
+        t.o2 = self.empty(M, hx)
+        t.lse2 = self.empty(B, bp.xheads, S, dtype=F32)
+        ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc,
+                            hx, 2 * hx, 2 * hx, hx)
+        hip.check(L.md_attn_fwd(byref(ax), st), "md_attn_fwd")
+        x2 = self.empty(M, d)
+        self.lin_fwd(t.o2, n + ".cross_attn.proj", x2, M, d, hx, mode=hip.EPI_RESIDUAL, res=x1)
+        t.x2 = x2
+        # -- feed-forward: x3 = x2 + gate_mlp * mlp(modulate(LN3(x2)))
+        t.xm3 = self.empty(M, d)
+        t.st3 = self.empty(2, M, dtype=F32)
+        self.ln_fwd(self.ln_args(x2, n + ".norm3", t.xm3, M, d, shift=mp + 2 * 3 * d, scale=mp + 2 * 4 * d, ldmod=6 * d,
+                                 rps=S, mean=t.st3[0], rstd=t.st3[1]))
+        x3 = self.empty(M, d)
+        t.br3 = self.empty(M, d)
+        gate_mlp = mp + 2 * 5 * d
+        if not bp.moe:
+            t.h12 = self.empty(M, 2 * f)
+            self.lin_fwd(t.xm3, n + ".mlp.w1", t.h12, M, f, d, ldc=2 * f)
+            self.lin_fwd(t.xm3, n + ".mlp.w2", t.h12, M, f, d, ldc=2 * f, ooff=f)
+            t.a = self.empty(M, f)
+            hip.check(L.md_swiglu_fwd(t.h12.data_ptr(), 2 * f, t.a.data_ptr(), f, M, f, st), "swiglu")
+            self.lin_fwd(t.a, n + ".mlp.w3", x3, M, d, f, mode=hip.EPI_RESIDUAL, res=x2, gate=gate_mlp, ldg=6 * d, rps=S,
+                         C2=t.br3)
+        else:
+            E = cfg.num_experts
+            k = int(cfg.expert_capacity * S / E)
+            ldl = 8 if E <= 8 else 16
+            Bk = B * k
+            t.k, t.ldl = k, ldl
+            logits = self.empty(M, ldl, dtype=F32)
+            self.lin_fwd(t.xm3, n + ".mlp.gate", logits, M, E, d, ldc=ldl, mode=hip.EPI_STORE_F32)
+            t.probs = self.empty(M, ldl, dtype=F32)
+            t.rowidx = self.empty(E, Bk, dtype=I32)
+            t.gval = self.empty(E, Bk, dtype=F32)
+            t.slot = self.empty(M, E, dtype=I32)
+            hip.check(L.md_moe_route(logits.data_ptr(), t.probs.data_ptr(), ldl, B, S, E, k, t.rowidx.data_ptr(),
+                                     t.gval.data_ptr(), t.slot.data_ptr(), st), "moe_route")
+            t.xin = self.empty(E, Bk, d)
+            hip.check(L.md_gather_rows(t.xm3.data_ptr(), d, t.rowidx.data_ptr(), t.xin.data_ptr(), d, E * Bk, d, st), "gather")
+            t.hpre = self.empty(E, Bk, f)
+            t.hact = self.empty(E, Bk, f)
+            w1, w2 = self.S[n + ".mlp.w1"], self.S[n + ".mlp.w2"]       # [E, d, f], [E, f, d]
+            self._gemm(A=t.xin.data_ptr(), B=w1.data_ptr(), C=t.hact.data_ptr(), C2=t.hpre.data_ptr(), M=Bk, N=f, K=d, lda=d,
+                       ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f, sC2=Bk * f, batch=E, ksplit=1, a_kcontig=1,
+                       b_kcontig=0, mode=hip.EPI_STORE_BF16, act=hip.ACT_GELU_ERF, alpha=1.0)
+            t.h2 = self.empty(E, Bk, d)
+            self._gemm(A=t.hact.data_ptr(), B=w2.data_ptr(), C=t.h2.data_ptr(), M=Bk, N=d, K=f, lda=f, ldb=d, ldc=d,
+                       sA=Bk * f, sB=f * d, sC=Bk * d, batch=E, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_STORE_BF16,
+                       act=0, alpha=1.0)
+            hip.check(L.md_moe_combine(t.h2.data_ptr(), t.gval.data_ptr(), t.slot.data_ptr(), x2.data_ptr(), gate_mlp, 6 * d,
+                                       t.br3.data_ptr(), x3.data_ptr(), B, S, E, k, d, st), "moe_combine")
+        return x3, t
+
+    def _block_bwd(self, bp: BlockPlan, t: Tape, dx, ycond, dycond_f32, B, S, Lc, gc, dgc_f32):
+        """dx: grad w.r.t. the block output [M, d] (bf16), updated IN PLACE to the grad w.r.t. the block input."""
+        L, st, cfg = self.L, self._st(), self.cfg
+        d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
+        M, Mc, D = B * S, B * Lc, cfg.dim
+        n = bp.name
+        mp = t.mod.data_ptr()
+        dmod = self.zeros(B, 6 * d)          # fp32 grads of (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp)
+        dmp = dmod.data_ptr()
+        rpb = 64 if S >= 64 else S
+        # ---------------- feed-forward branch
+        dbr3 = self.empty(M, d)
+        hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, 6 * d, dbr3.data_ptr(), dmp + 4 * 5 * d, 6 * d,
+                                M, d, S, rpb, st), "gate_bwd")
+        dxm3 = self.empty(M, d)
+        if not bp.moe:
+            self.lin_wgrad(dbr3, t.a, n + ".mlp.w3", M, d, f)
+            da = self.empty(M, f)
+            self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
+            dh12 = self.empty(M, 2 * f)
+            hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd")
+            self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, f, d, lddy=2 * f)
+            self.lin_wgrad(dh12, t.xm3, n + ".mlp.w2", M, f, d, lddy=2 * f, dyoff=f)
+            self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, f, d, lddy=2 * f)
+            self.lin_dgrad(dh12, n + ".mlp.w2", dxm3, M, f, d, lddy=2 * f, dyoff=f, mode=hip.EPI_RESIDUAL, res=dxm3)
+        else:
+            E, k, ldl = cfg.num_experts, t.k, t.ldl
+            Bk = B * k
+            w1, w2 = self.S[n + ".mlp.w1"], self.S[n + ".mlp.w2"]
+            g1, g2 = self.G[n + ".mlp.w1"], self.G[n + ".mlp.w2"]
+            dh2 = self.empty(E, Bk, d)
+            dgval = self.empty(E, Bk, dtype=F32)
+            hip.check(L.md_moe_combine_bwd(dbr3.data_ptr(), t.h2.data_ptr(), t.rowidx.data_ptr(), t.gval.data_ptr(),
+                                           dh2.data_ptr(), dgval.data_ptr(), E * Bk, d, st), "combine_bwd")
+            ks = self._ksplit(f, d, Bk)
+            emode = hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32
+            # dW2[e][f, d] += hact[e]^T dh2[e]
+            self._gemm(A=t.hact.data_ptr(), B=dh2.data_ptr(), C=g2.data_ptr(), M=f, N=d, K=Bk, lda=f, ldb=d, ldc=d, sA=Bk * f,
+                       sB=Bk * d, sC=f * d, batch=E, ksplit=ks, a_kcontig=0, b_kcontig=0, mode=emode, act=0, alpha=1.0)
+            # dhpre = (dh2 @ W2[e]^T) * gelu'(hpre)
+            dhpre = self.empty(E, Bk, f)
+            self._gemm(A=dh2.data_ptr(), B=w2.data_ptr(), C=dhpre.data_ptr(), aux=t.hpre.data_ptr(), M=Bk, N=f, K=d, lda=d,
+                       ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d, sC=Bk * f, sAux=Bk * f, batch=E, ksplit=1, a_kcontig=1,
+                       b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, alpha=1.0)
+            # dW1[e][d, f] += xin[e]^T dhpre[e]
+            self._gemm(A=t.xin.data_ptr(), B=dhpre.data_ptr(), C=g1.data_ptr(), M=d, N=f, K=Bk, lda=d, ldb=f, ldc=f,
+                       sA=Bk * d, sB=Bk * f, sC=d * f, batch=E, ksplit=ks, a_kcontig=0, b_kcontig=0, mode=emode, act=0, alpha=1.0)
+            # dxin = dhpre @ W1[e]^T
+            dxin = self.empty(E, Bk, d)
+            self._gemm(A=dhpre.data_ptr(), B=w1.data_ptr(), C=dxin.data_ptr(), M=Bk, N=d, K=f, lda=f, ldb=f, ldc=d, sA=Bk * f,
+                       sB=d * f, sC=Bk * d, batch=E, ksplit=1, a_kcontig=1, b_kcontig=1, mode=hip.EPI_STORE_BF16, act=0, alpha=1.0)
+            dlog = self.empty(M, ldl)
+            hip.check(L.md_moe_dispatch_bwd(dxin.data_ptr(), t.slot.data_ptr(), dxm3.data_ptr(), t.probs.data_ptr(), ldl,
+                                            dgval.data_ptr(), dlog.data_ptr(), ldl, B, S, E, k, d, st), "dispatch_bwd")
+            # gate: dWg[E, d] += dlog^T xm3 ; dxm3 += dlog @ Wg
+            self.lin_wgrad(dlog, t.xm3, n + ".mlp.gate", M, E, d, lddy=ldl)
+            self.lin_dgrad(dlog, n + ".mlp.gate", dxm3, M, E, d, lddy=ldl, mode=hip.EPI_RESIDUAL, res=dxm3)
+        a3 = self.ln_args(t.x2, n + ".norm3", None, M, d, scale=mp + 2 * 4 * d, ldmod=6 * d, rps=S, mean=t.st3[0], rstd=t.st3[1])
+        self.ln_bwd(a3, dxm3, dx, accumulate=True, wname=n + ".norm3", dscale=dmp + 4 * 4 * d, dshift=dmp + 4 * 3 * d, ldg=6 * d)
+        # ---------------- cross-attention branch (un-gated, un-modulated)
+        self.lin_wgrad(dx, t.o2, n + ".cross_attn.proj", M, d, hx)
+        do2 = self.empty(M, hx)
+        self.lin_dgrad(dx, n + ".cross_attn.proj", do2, M, d, hx)
+        dq2 = self.empty(M, hx)
+        dkv = self.empty(Mc, 2 * hx)
+        delta = self.empty(B, bp.xheads, S, dtype=F32)
+        ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, hx,
+                            2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
+                            delta=delta, lddq=hx, lddk=2 * hx, lddv=2 * hx)
+        hip.check(L.md_attn_bwd(byref(ax), st), "md_attn_bwd")
+        hip.check(L.md_qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr(), st), "qkln_bwd")
+        hip.check(L.md_qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr(), st), "qkln_bwd")
+        self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)
+        self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
+        # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens
+        self._gemm(A=dkv.data_ptr(), B=self.S[n + ".cross_attn.kv_linear.weight"].data_ptr(), C=dycond_f32.data_ptr(), M=Mc,
+                   N=d, K=2 * hx, lda=2 * hx, ldb=d, ldc=d, batch=1, ksplit=1, a_kcontig=1, b_kcontig=0,
+                   mode=hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        dxn2 = self.empty(M, d)
+        self.lin_dgrad(dq2, n + ".cross_attn.q_linear", dxn2, M, hx, d)
+        a2 = self.ln_args(t.x1, n + ".norm2", None, M, d, mean=t.st2[0], rstd=t.st2[1], rps=S)
+        self.ln_bwd(a2, dxn2, dx, accumulate=True, wname=n + ".norm2")
+        # ---------------- self-attention branch
+        dbr1 = self.empty(M, d)
+        hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, 6 * d, dbr1.data_ptr(), dmp + 4 * 2 * d, 6 * d,
+                                M, d, S, rpb, st), "gate_bwd")
+        self.lin_wgrad(dbr1, t.sa.o, n + ".attn.proj", M, d, h)
+        do = self.empty(M, h)
+        self.lin_dgrad(dbr1, n + ".attn.proj", do, M, d, h)
+        dxm1 = self._self_attn_bwd(n + ".attn", t.xm1, do, B, S, d, h, bp.heads, t.sa)
+        a1 = self.ln_args(t.x, n + ".norm1", None, M, d, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
+        self.ln_bwd(a1, dxm1, dx, accumulate=True, wname=n + ".norm1", dscale=dmp + 4 * d, dshift=dmp, ldg=6 * d)
+        # ---------------- adaLN linear: mod = W gelu(c) + b
+        self._adaln_bwd(n + ".adaLN_modulation.1", dmod, B, 6 * d, gc, dgc_f32)
+
+    def _adaln_bwd(self, wname, dmod_f32, B, N, gc, dgc_f32):
+        D = self.cfg.dim
+        dmod = self.empty(B, N)
+        hip.check(self.L.md_cast_f32_bf16(dmod_f32.data_ptr(), dmod.data_ptr(), B * N, None, self._st()), "cast")
+        self.lin_wgrad(dmod, gc, wname, B, N, D, bias_from=dmod_f32)
+        self._gemm(A=dmod.data_ptr(), B=self.S[wname + ".weight"].data_ptr(), C=dgc_f32.data_ptr(), M=B, N=D, K=N, lda=N,
+                   ldb=D, ldc=D, batch=1, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+
+    # ------------------------------------------------------------------------------------------ small MLPs (Mlp with norm)
+    def _mlp_norm_fwd(self, pre, xin, rows, cin, rps, res=None):
+        """fc2(LN(gelu(fc1(x)))) (utils.py:63-68); optional residual add on the output.  Returns (out, tape)."""
+        D = self.cfg.dim
+        t = Tape()
+        t.xin = xin
+        t.h = self.empty(rows, D)
+        self.lin_fwd(xin, pre + ".fc1", t.h, rows, D, cin)
+        t.hn = self.empty(rows, D)
+        t.st = self.empty(2, rows, dtype=F32)
+        self.ln_fwd(self.ln_args(t.h, pre + ".norm", t.hn, rows, D, mean=t.st[0], rstd=t.st[1], act=hip.ACT_GELU_TANH, rps=rps))
+        out = self.empty(rows, D)
+        if res is None:
+            self.lin_fwd(t.hn, pre + ".fc2", out, rows, D, D)
+        else:
+            self.lin_fwd(t.hn, pre + ".fc2", out, rows, D, D, mode=hip.EPI_RESIDUAL, res=res)
+        return out, t
+
+    def _mlp_norm_bwd(self, pre, t, dout, rows, cin, rps, need_dx):
+        D = self.cfg.dim
+        self.lin_wgrad(dout, t.hn, pre + ".fc2", rows, D, D)
+        dhn = self.empty(rows, D)
+        self.lin_dgrad(dout, pre + ".fc2", dhn, rows, D, D)
+        dh = self.empty(rows, D)
+        a = self.ln_args(t.h, pre + ".norm", None, rows, D, mean=t.st[0], rstd=t.st[1], act=hip.ACT_GELU_TANH, rps=rps)
+        self.ln_bwd(a, dhn, dh, accumulate=False, wname=pre + ".norm")
+        self.lin_wgrad(dh, t.xin, pre + ".fc1", rows, D, cin)
+        if not need_dx:
+            return None
+        dx = self.empty(rows, cin)
+        self.lin_dgrad(dh, pre + ".fc1", dx, rows, D, cin)
+        return dx
+
+    # ------------------------------------------------------------------------------------------ whole model
+    def forward(self, x_img: torch.Tensor, t_in: torch.Tensor, y: torch.Tensor, *, mask_ratio: float = 0.0,
+                mask_noise: Optional[torch.Tensor] = None, in_scale: Optional[torch.Tensor] = None,
+                y_rowscale: Optional[torch.Tensor] = None) -> Tape:
+        """x_img f32 [B,C,H,W] (multiplied by in_scale[b] if given), t_in f32 [B], y f16|f32 [B,(1,)L,Dc]
+        (rows multiplied by y_rowscale[b] if given).  Returns the tape; tape.tok is the network output for the
+        kept tokens, bf16 [B*Tk, p*p*C]."""
+        cfg, L, st = self.cfg, self.L, self._st()
+        B = x_img.shape[0]
+        C, H, W, p = cfg.in_channels, x_img.shape[-2], x_img.shape[-1], cfg.patch_size
+        T, D, Dm = (H // p) * (W // p), cfg.dim, cfg.patch_mixer_dim
+        assert T == cfg.tokens, "input resolution does not match the model's position table"
+        Lc, Dc = y.shape[-2], y.shape[-1]
+        assert x_img.dtype == F32 and x_img.is_contiguous() and y.is_contiguous() and y.dtype in (torch.float16, F32)
+        tp = Tape()
+        tp.B, tp.T, tp.Lc, tp.H, tp.W = B, T, Lc, H, W
+        # ---- patch embedding (+ pos), dit.py:479
+        tp.patches = self.empty(B * T, cfg.patch_vec)
+        hip.check(L.md_patchify(x_img.data_ptr(), _p(in_scale), tp.patches.data_ptr(), B, C, H, W, p, st), "patchify")
+        tok = self.empty(B * T, D)
+        self._gemm(A=tp.patches.data_ptr(), B=self.S["x_embedder.proj.weight"].data_ptr(), C=tok.data_ptr(),
+                   bias=self.P["x_embedder.proj.bias"].data_ptr(), M=B * T, N=D, K=cfg.patch_vec, lda=cfg.patch_vec,
+                   ldb=cfg.patch_vec, ldc=D, batch=1, ksplit=1, a_kcontig=1, b_kcontig=1, mode=hip.EPI_STORE_BF16, act=0, alpha=1.0)
+        tp.tok = tok
+        # ---- timestep embedding, dit.py:480
+        tp.tfreq = self.empty(B, 512)
+        t_f = t_in.to(F32).expand(B).contiguous()
+        hip.check(L.md_timestep_embed(t_f.data_ptr(), tp.tfreq.data_ptr(), B, 512, st), "timestep_embed")
+        tp.t_pre = self.empty(B, D)
+        tp.t_h = self.empty(B, D)
+        self.lin_fwd(tp.tfreq, "t_embedder.mlp.0", tp.t_h, B, D, 512, act=hip.ACT_GELU_TANH, C2=tp.t_pre)
+        temb = self.empty(B, D)
+        self.lin_fwd(tp.t_h, "t_embedder.mlp.2", temb, B, D, D)
+        # ---- caption projection + caption block, dit.py:482-483
+        Mc = B * Lc
+        tp.ycap = self.empty(Mc, Dc)
+        hip.check(L.md_cast_rows_bf16(y.data_ptr(), 0 if y.dtype == torch.float16 else 1, tp.ycap.data_ptr(), Mc, Dc,
+                                      _p(y_rowscale), Lc, st), "cast_rows")
+        y0, tp.yproj = self._mlp_norm_fwd("y_embedder.y_proj", tp.ycap, Mc, Dc, Lc)
+        tp.y0 = y0
+        cb = Tape()
+        cb.xn1 = self.empty(Mc, D)
+        cb.st1 = self.empty(2, Mc, dtype=F32)
+        self.ln_fwd(self.ln_args(y0, "y_emb_preprocess.norm1", cb.xn1, Mc, D, mean=cb.st1[0], rstd=cb.st1[1], rps=Lc))
+        cb.sa = Tape()
+        heads_c = D // cfg.head_dim
+        o = self._self_attn_fwd("y_emb_preprocess.attn", cb.xn1, B, Lc, D, D, heads_c, cb.sa)
+        y1 = self.empty(Mc, D)
+        self.lin_fwd(o, "y_emb_preprocess.attn.proj", y1, Mc, D, D, mode=hip.EPI_RESIDUAL, res=y0)
+        cb.y1 = y1
+        cb.xn2 = self.empty(Mc, D)
+        cb.st2 = self.empty(2, Mc, dtype=F32)
+        self.ln_fwd(self.ln_args(y1, "y_emb_preprocess.norm2", cb.xn2, Mc, D, mean=cb.st2[0], rstd=cb.st2[1], rps=Lc))
+        fc = caption_ffn_hidden(cfg)
+        cb.h12 = self.empty(Mc, 2 * fc)
+        self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w1", cb.h12, Mc, fc, D, ldc=2 * fc)
+        self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w2", cb.h12, Mc, fc, D, ldc=2 * fc, ooff=fc)
+        cb.a = self.empty(Mc, fc)
+        hip.check(L.md_swiglu_fwd(cb.h12.data_ptr(), 2 * fc, cb.a.data_ptr(), fc, Mc, fc, st), "swiglu")
+        y2 = self.empty(Mc, D)
+        self.lin_fwd(cb.a, "y_emb_preprocess.mlp.w3", y2, Mc, D, fc, mode=hip.EPI_RESIDUAL, res=y1)
+        tp.cb, tp.y2 = cb, y2
+        # ---- pooled caption -> condition vector c = t_emb + Mlp(mean(y)), dit.py:484-485
+        tp.ymean = self.empty(B, D)
+        hip.check(L.md_mean_tokens(y2.data_ptr(), tp.ymean.data_ptr(), B, Lc, D, st), "mean_tokens")
+        c, tp.pool = self._mlp_norm_fwd("pooled_y_emb_process", tp.ymean, B, D, 1, res=temb)
+        tp.c = c
+        gc = self.empty(B, D)
+        hip.check(L.md_act_fwd(c.data_ptr(), gc.data_ptr(), B * D, hip.ACT_GELU_TANH, st), "act_fwd")
+        tp.gc = gc
+        # ---- patch mixer, dit.py:489-493
+        pos = self.buf["pos_embed"]
+        if cfg.use_patch_mixer and cfg.has_maps:
+            tp.xin_ln = self.empty(B * T, D)
+            tp.st_xin = self.empty(2, B * T, dtype=F32)
+            self.ln_fwd(self.ln_args(tok, "patch_mixer_map_xin.0", tp.xin_ln, B * T, D, mean=tp.st_xin[0], rstd=tp.st_xin[1],
+                                     pos=pos, pos_rows=T, rps=T))
+            x = self.empty(B * T, Dm)
+            self.lin_fwd(tp.xin_ln, "patch_mixer_map_xin.1", x, B * T, Dm, D)
+            tp.y_ln = self.empty(Mc, D)
+            tp.st_y = self.empty(2, Mc, dtype=F32)
+            self.ln_fwd(self.ln_args(y2, "patch_mixer_map_y.0", tp.y_ln, Mc, D, mean=tp.st_y[0], rstd=tp.st_y[1], rps=Lc))
+            ym = self.empty(Mc, Dm)
+            self.lin_fwd(tp.y_ln, "patch_mixer_map_y.1", ym, Mc, Dm, D)
+        else:
+            # Identity maps (patch_mixer_dim == dim, dit.py:389-392): x = tok + pos
+            x = self.empty(B * T, D)
+            posb = pos.to(BF16).expand(B, T, D).contiguous()
+            hip.check(L.md_add_bf16(tok.data_ptr(), posb.data_ptr(), x.data_ptr(), B * T * D, st), "add")
+            ym = y2
+        tp.ym = ym
+        tp.mixer = []
+        for bp in self.mixer:
+            x, bt = self._block_fwd(bp, x, ym, B, T, Lc, gc)
+            tp.mixer.append(bt)
+        # ---- masking, dit.py:495-504
+        Wd = x.shape[1]
+        if mask_ratio > 0:
+            Tk = int(T * (1 - mask_ratio))
+            assert mask_noise is not None and mask_noise.dtype == F32 and mask_noise.shape == (B, T)
+            tp.keep_rows = self.empty(B * Tk, dtype=I32)
+            tp.ids_restore = self.empty(B, T, dtype=I32)
+            tp.mask = self.empty(B, T, dtype=F32)
+            hip.check(L.md_get_mask(mask_noise.contiguous().data_ptr(), B, T, Tk, tp.keep_rows.data_ptr(),
+                                    tp.ids_restore.data_ptr(), tp.mask.data_ptr(), st), "get_mask")
+            xk = self.empty(B * Tk, Wd)
+            hip.check(L.md_gather_rows(x.data_ptr(), Wd, tp.keep_rows.data_ptr(), xk.data_ptr(), Wd, B * Tk, Wd, st), "gather")
+            x = xk
+        else:
+            Tk = T
+            tp.keep_rows = tp.ids_restore = tp.mask = None
+        tp.Tk = Tk
+        # ---- mixer -> backbone projection (after masking), dit.py:506-508
+        if cfg.use_patch_mixer and cfg.has_maps:
+            tp.xout_in = x
+            tp.xout_ln = self.empty(B * Tk, Dm)
+            tp.st_xout = self.empty(2, B * Tk, dtype=F32)
+            self.ln_fwd(self.ln_args(x, "patch_mixer_map_xout.0", tp.xout_ln, B * Tk, Dm, mean=tp.st_xout[0],
+                                     rstd=tp.st_xout[1], rps=Tk))
+            xb = self.empty(B * Tk, D)
+            self.lin_fwd(tp.xout_ln, "patch_mixer_map_xout.1", xb, B * Tk, D, Dm)
+            x = xb
+        tp.blocks = []
+        for bp in self.backbone:
+            x, bt = self._block_fwd(bp, x, y2, B, Tk, Lc, gc)
+            tp.blocks.append(bt)
+        # ---- final layer, dit.py:513
+        tp.xlast = x
+        tp.fmod = self.empty(B, 2 * D)
+        self.lin_fwd(gc, "final_layer.adaLN_modulation.1", tp.fmod, B, 2 * D, D)
+        fm = tp.fmod.data_ptr()
+        tp.xf = self.empty(B * Tk, D)
+        tp.st_f = self.empty(2, B * Tk, dtype=F32)
+        self.ln_fwd(self.ln_args(x, "final_layer.norm_final", tp.xf, B * Tk, D, shift=fm, scale=fm + 2 * D, ldmod=2 * D, rps=Tk,
+                                 mean=tp.st_f[0], rstd=tp.st_f[1]))
+        pv = cfg.patch_vec
+        tp.out_tok = self.empty(B * Tk, pv)
+        self.lin_fwd(tp.xf, "final_layer.linear", tp.out_tok, B * Tk, pv, D)
+        return tp
+
+    def sample_image(self, tp: Tape) -> torch.Tensor:
+        """unmask_tokens + unpatchify (utils.py:417-426, dit.py:566-575) -> f32 [B, C, H, W]."""
+        cfg = self.cfg
+        img = self.empty(tp.B, cfg.in_channels, tp.H, tp.W, dtype=F32)
+        mt = self.buf["mask_token"]
+        hip.check(self.L.md_unpatchify(tp.out_tok.data_ptr(), _p(tp.ids_restore), tp.Tk, mt.data_ptr(), img.data_ptr(), tp.B,
+                                       cfg.in_channels, tp.H, tp.W, cfg.patch_size, self._st()), "unpatchify")
+        return img
+
+    def backward(self, tp: Tape, dtok: torch.Tensor) -> None:
+        """dtok: bf16 [B*Tk, p*p*C] grad of the network output for the kept tokens.  Accumulates every parameter
+        gradient into the fp32 grad buffers (self.G)."""
+        cfg, L, st = self.cfg, self.L, self._st()
+        B, T, Tk, Lc = tp.B, tp.T, tp.Tk, tp.Lc
+        D, Dm, pv = cfg.dim, cfg.patch_mixer_dim, cfg.patch_vec
+        Mc = B * Lc
+        gc = tp.gc
+        dgc = self.zeros(B, D)                      # fp32: sums the adaLN dgrads of all 6+28+1 layers
+        dy2_f32 = self.zeros(Mc, D)                 # fp32: caption-token grads from the 28 backbone kv_linears + pooling
+        # ---- final layer
+        self.lin_wgrad(dtok, tp.xf, "final_layer.linear", B * Tk, pv, D)
+        dxf = self.empty(B * Tk, D)
+        self.lin_dgrad(dtok, "final_layer.linear", dxf, B * Tk, pv, D)
+        dfm = self.zeros(B, 2 * D)
+        fm = tp.fmod.data_ptr()
+        dx = self.empty(B * Tk, D)
+        af = self.ln_args(tp.xlast, "final_layer.norm_final", None, B * Tk, D, scale=fm + 2 * D, ldmod=2 * D, rps=Tk,
+                          mean=tp.st_f[0], rstd=tp.st_f[1])
+        self.ln_bwd(af, dxf, dx, accumulate=False, wname="final_layer.norm_final", dscale=dfm.data_ptr() + 4 * D,
+                    dshift=dfm.data_ptr(), ldg=2 * D)
+        self._adaln_bwd("final_layer.adaLN_modulation.1", dfm, B, 2 * D, gc, dgc)
+        # ---- backbone
+        for bp, bt in zip(reversed(self.backbone), reversed(tp.blocks)):
+            self._block_bwd(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc)
+        # ---- mixer -> backbone projection
+        if cfg.use_patch_mixer and cfg.has_maps:
+            self.lin_wgrad(dx, tp.xout_ln, "patch_mixer_map_xout.1", B * Tk, D, Dm)
+            dln = self.empty(B * Tk, Dm)
+            self.lin_dgrad(dx, "patch_mixer_map_xout.1", dln, B * Tk, D, Dm)
+            dxk = self.empty(B * Tk, Dm)
+            a = self.ln_args(tp.xout_in, "patch_mixer_map_xout.0", None, B * Tk, Dm, mean=tp.st_xout[0], rstd=tp.st_xout[1], rps=Tk)
+            self.ln_bwd(a, dln, dxk, accumulate=False, wname="patch_mixer_map_xout.0")
+            dx = dxk
+        Wd = dx.shape[1]
+        # ---- un-mask: scatter kept-token grads back to all T positions (zeros elsewhere)
+        if tp.keep_rows is not None:
+            dfull = torch.zeros(B * T, Wd, device=self.dev, dtype=BF16)
+            hip.check(L.md_scatter_rows(dx.data_ptr(), Wd, tp.keep_rows.data_ptr(), dfull.data_ptr(), Wd, B * Tk, Wd, st), "scatter")
+            dx = dfull
+        # ---- patch mixer
+        has_maps = cfg.use_patch_mixer and cfg.has_maps
+        dym_f32 = self.zeros(Mc, Dm) if has_maps else dy2_f32
+        for bp, bt in zip(reversed(self.mixer), reversed(tp.mixer)):
+            self._block_bwd(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc)
+        # ---- map_xin / patch embedding
+        if has_maps:
+            self.lin_wgrad(dx, tp.xin_ln, "patch_mixer_map_xin.1", B * T, Dm, D)
+            dln = self.empty(B * T, D)
+            self.lin_dgrad(dx, "patch_mixer_map_xin.1", dln, B * T, Dm, D)
+            dtok_e = self.empty(B * T, D)
+            a = self.ln_args(tp.tok, "patch_mixer_map_xin.0", None, B * T, D, mean=tp.st_xin[0], rstd=tp.st_xin[1],
+                             pos=self.buf["pos_embed"], pos_rows=T, rps=T)
+            self.ln_bwd(a, dln, dtok_e, accumulate=False, wname="patch_mixer_map_xin.0")
+        else:
+            dtok_e = dx
+        ks = self._ksplit(D, pv, B * T)
+        self._gemm(A=dtok_e.data_ptr(), B=tp.patches.data_ptr(), C=self.G["x_embedder.proj.weight"].data_ptr(), M=D, N=pv,
+                   K=B * T, lda=D, ldb=pv, ldc=pv, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
+                   mode=hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        hip.check(L.md_colsum(dtok_e.data_ptr(), 0, D, self.G["x_embedder.proj.bias"].data_ptr(), B * T, D, st), "colsum")
+        # ---- condition vector: c = temb + pooled ; gc = gelu(c)
+        dc = self.empty(B, D)
+        hip.check(L.md_act_bwd(dgc.data_ptr(), tp.c.data_ptr(), dc.data_ptr(), B * D, hip.ACT_GELU_TANH, st), "act_bwd")
+        # timestep embedder
+        self.lin_wgrad(dc, tp.t_h, "t_embedder.mlp.2", B, D, D)
+        dtpre = self.empty(B, D)
+        self.lin_dgrad(dc, "t_embedder.mlp.2", dtpre, B, D, D, mode=hip.EPI_DACT, act=hip.ACT_GELU_TANH, aux=tp.t_pre)
+        self.lin_wgrad(dtpre, tp.tfreq, "t_embedder.mlp.0", B, D, 512)
+        # pooled-caption MLP -> mean over tokens
+        dymean = self._mlp_norm_bwd("pooled_y_emb_process", tp.pool, dc, B, D, 1, need_dx=True)
+        hip.check(L.md_mean_tokens_bwd(dymean.data_ptr(), dy2_f32.data_ptr(), B, Lc, D, st), "mean_bwd")
+        # ---- caption tokens: total grad w.r.t. y2
+        dy = self.empty(Mc, D)
+        hip.check(L.md_cast_f32_bf16(dy2_f32.data_ptr(), dy.data_ptr(), Mc * D, None, st), "cast")
+        if has_maps:
+            dym = self.empty(Mc, Dm)
+            hip.check(L.md_cast_f32_bf16(dym_f32.data_ptr(), dym.data_ptr(), Mc * Dm, None, st), "cast")
+            self.lin_wgrad(dym, tp.y_ln, "patch_mixer_map_y.1", Mc, Dm, D)
+            dyl = self.empty(Mc, D)
+            self.lin_dgrad(dym, "patch_mixer_map_y.1", dyl, Mc, Dm, D)
+            a = self.ln_args(tp.y2, "patch_mixer_map_y.0", None, Mc, D, mean=tp.st_y[0], rstd=tp.st_y[1], rps=Lc)
+            self.ln_bwd(a, dyl, dy, accumulate=True, wname="patch_mixer_map_y.0")
+        # ---- caption block (y2 = y1 + ffn(LN2(y1)); y1 = y0 + attn(LN1(y0)))
+        cb = tp.cb
+        fc = caption_ffn_hidden(cfg)
+        self.lin_wgrad(dy, cb.a, "y_emb_preprocess.mlp.w3", Mc, D, fc)
+        da = self.empty(Mc, fc)
+        self.lin_dgrad(dy, "y_emb_preprocess.mlp.w3", da, Mc, D, fc)
+        dh12 = self.empty(Mc, 2 * fc)
+        hip.check(L.md_swiglu_bwd(da.data_ptr(), fc, cb.h12.data_ptr(), 2 * fc, dh12.data_ptr(), 2 * fc, Mc, fc, st), "swiglu_bwd")
+        self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w1", Mc, fc, D, lddy=2 * fc)
+        self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w2", Mc, fc, D, lddy=2 * fc, dyoff=fc)
+        dxn2 = self.empty(Mc, D)
+        self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w1", dxn2, Mc, fc, D, lddy=2 * fc)
+        self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w2", dxn2, Mc, fc, D, lddy=2 * fc, dyoff=fc, mode=hip.EPI_RESIDUAL, res=dxn2)
+        a = self.ln_args(cb.y1, "y_emb_preprocess.norm2", None, Mc, D, mean=cb.st2[0], rstd=cb.st2[1], rps=Lc)
+        self.ln_bwd(a, dxn2, dy, accumulate=True, wname="y_emb_preprocess.norm2")
+        heads_c = D // cfg.head_dim
+        self.lin_wgrad(dy, cb.sa.o, "y_emb_preprocess.attn.proj", Mc, D, D)
+        do = self.empty(Mc, D)
+        self.lin_dgrad(dy, "y_emb_preprocess.attn.proj", do, Mc, D, D)
+        dxn1 = self._self_attn_bwd("y_emb_preprocess.attn", cb.xn1, do, B, Lc, D, D, heads_c, cb.sa)
+        a = self.ln_args(tp.y0, "y_emb_preprocess.norm1", None, Mc, D, mean=cb.st1[0], rstd=cb.st1[1], rps=Lc)
+        self.ln_bwd(a, dxn1, dy, accumulate=True, wname="y_emb_preprocess.norm1")
+        # ---- caption projection (inputs need no grad)
+        self._mlp_norm_bwd("y_embedder.y_proj", tp.yproj, dy, Mc, tp.ycap.shape[1], Lc, need_dx=False)

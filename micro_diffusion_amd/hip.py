@@ -99,6 +99,12 @@ def lib() -> ctypes.CDLL:
     """Load (once) the in-tree shared library; raise loudly when it is absent."""
     global _lib
     if _lib is None:
+        stale = True
+        if os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH):
+            with open(_HASH_PATH) as fh:
+                stale = fh.read().strip() != _source_hash()
+        if stale and (os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC")):
+            build()                      # sources changed since the last build: never run a stale library
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the MicroDiT HIP extension has not been built. "

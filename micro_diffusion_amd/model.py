@@ -1,0 +1,299 @@
+"""Drop-in `LatentDiffusion` / `create_latent_diffusion` (reference micro_diffusion/models/model.py:22-405).
+
+Training path (`forward(batch)` -> EDM loss): sigma sampling, noise add, preconditioning, the whole DiT, the
+masked-patch loss and the complete backward run as HIP kernels (engine.py); PyTorch supplies the random draws (in
+the reference's order: randn[B,1,1,1], randn_like(x), rand[B,T]) and the autograd hook (`loss.backward()`).
+Sampling (`edm_sampler_loop` / `generate`) is inference-only glue around the same HIP forward.
+"""
+from __future__ import annotations
+
+from functools import partial
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dit as model_zoo
+from . import hip
+
+DATA_TYPES = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}
+
+
+def text_encoder_embedding_format(enc: str):
+    """(sequence length, embedding dim) of the supported text encoders (reference utils.py:501-513)."""
+    if enc in ("stabilityai/stable-diffusion-2-base", "runwayml/stable-diffusion-v1-5", "CompVis/stable-diffusion-v1-4",
+               "openclip:hf-hub:apple/DFN5B-CLIP-ViT-H-14-378"):
+        return 77, 1024
+    if enc == "DeepFloyd/t5-v1_1-xxl":
+        return 120, 4096
+    raise ValueError(f"Please specify the sequence and embedding size of {enc} encoder")
+
+
+class DistLoss:
+    """Running mean of the per-batch losses (reference utils.py:598-614, without the torchmetrics dependency)."""
+
+    def __init__(self):
+        self.loss, self.batches = 0.0, 0
+
+    def update(self, value):
+        self.loss = self.loss + value.detach()
+        self.batches += 1
+
+    def compute(self):
+        return self.loss.float() / self.batches
+
+
+class _EDMConfig(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class LatentDiffusion(nn.Module):
+    def __init__(self, dit: nn.Module, vae, text_encoder, tokenizer, image_key: str = "image", text_key: str = "captions",
+                 image_latents_key: str = "image_latents", text_latents_key: str = "caption_latents",
+                 precomputed_latents: bool = True, dtype: str = "bfloat16", latent_res: int = 32, p_mean: float = -0.6,
+                 p_std: float = 1.2, train_mask_ratio: float = 0.0):
+        super().__init__()
+        self.dit = dit
+        self.vae = vae
+        self.image_key, self.text_key = image_key, text_key
+        self.image_latents_key, self.text_latents_key = image_latents_key, text_latents_key
+        self.precomputed_latents = precomputed_latents
+        self.dtype = dtype
+        self.latent_res = latent_res
+        self.edm_config = _EDMConfig(sigma_min=0.002, sigma_max=80, P_mean=p_mean, P_std=p_std, sigma_data=0.9, num_steps=18,
+                                     rho=7, S_churn=0, S_min=0, S_max=float("inf"), S_noise=1)
+        self.train_mask_ratio = train_mask_ratio
+        self.eval_mask_ratio = 0.0
+        assert self.train_mask_ratio >= 0, "Masking ratio must be non-negative!"
+        self.randn_like = torch.randn_like
+        self.latent_scale = self.vae.config.scaling_factor
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        for frozen in (self.text_encoder, self.vae):
+            if isinstance(frozen, nn.Module):
+                frozen.requires_grad_(False)
+
+    # ---------------------------------------------------------------------------------------- training step
+    def forward(self, batch: dict):
+        if self.precomputed_latents and self.image_latents_key in batch:
+            latents = batch[self.image_latents_key]        # already multiplied by the VAE scaling factor
+        else:
+            with torch.no_grad():
+                images = batch[self.image_key]
+                latents = self.vae.encode(images.to(DATA_TYPES[self.dtype]))["latent_dist"].sample().data
+                latents *= self.latent_scale
+        if self.precomputed_latents and self.text_latents_key in batch:
+            conditioning = batch[self.text_latents_key]
+        else:
+            captions = batch[self.text_key]
+            captions = captions.view(-1, captions.shape[-1])
+            if "attention_mask" in batch:
+                conditioning = self.text_encoder.encode(captions, attention_mask=batch["attention_mask"].view(-1, captions.shape[-1]))[0]
+            else:
+                conditioning = self.text_encoder.encode(captions)[0]
+        if "drop_caption_mask" in batch.keys():            # in place on the batch tensor, like model.py:132-135
+            conditioning *= batch["drop_caption_mask"].view([-1] + [1] * (len(conditioning.shape) - 1)).to(conditioning.dtype)
+        loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio)
+        return (loss, latents, conditioning)
+
+    def edm_loss(self, x: torch.Tensor, y: torch.Tensor, mask_ratio: float = 0, _noise=None, **kwargs) -> torch.Tensor:
+        """model.py:181-210 on the HIP engine.  `_noise=(rnd_normal, eps, mask_noise)` injects the three random
+        draws (parity tests); otherwise they are drawn here in the reference's order."""
+        dit = self.dit
+        dit._ensure_flat()
+        dit.refresh_shadow()
+        eng = dit._engine
+        cfg = self.edm_config
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        T = (x.shape[-2] // dit.patch_size) * (x.shape[-1] // dit.patch_size)
+        if _noise is None:
+            rnd = torch.randn([B, 1, 1, 1], device=x.device)
+            eps = self.randn_like(x)
+            mnoise = torch.rand(B, T, device=x.device) if mask_ratio > 0 else None
+        else:
+            rnd, eps, mnoise = _noise
+        if mask_ratio > 0:
+            assert dit.training, "Masking is only recommended during training"
+        y = y.detach()
+        if y.dtype not in (torch.float16, torch.float32):
+            y = y.float()
+        y = y.contiguous()
+        need_grad = torch.is_grad_enabled() and dit._plist[0].requires_grad
+        args = (self, dit._grad_anchor, x, y, rnd.reshape(B).float().contiguous(), eps.float().contiguous(), mnoise,
+                float(mask_ratio))
+        if need_grad:
+            return _EDMLossFunction.apply(*args)
+        return _edm_forward(*args)[0]
+
+    def model_forward_wrapper(self, x, sigma, y, model_forward_fxn, mask_ratio: float, **kwargs) -> dict:
+        """EDM preconditioning around an arbitrary forward fn (model.py:144-179); used by the sampler."""
+        sd = self.edm_config.sigma_data
+        sigma = sigma.to(x.dtype).reshape(-1, 1, 1, 1)
+        c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+        c_out = sigma * sd / (sigma ** 2 + sd ** 2).sqrt()
+        c_in = 1 / (sd ** 2 + sigma ** 2).sqrt()
+        c_noise = sigma.log() / 4
+        out = model_forward_fxn((c_in * x).to(x.dtype), c_noise.flatten(), y, mask_ratio=mask_ratio, **kwargs)
+        out["sample"] = c_skip * x + c_out * out["sample"]
+        return out
+
+    # Composer-style hooks (model.py:212-229)
+    def loss(self, outputs, batch):
+        return outputs[0]
+
+    def eval_forward(self, batch, outputs=None):
+        if outputs is not None:
+            return outputs
+        loss, _, _ = self.forward(batch)
+        return loss, None, None
+
+    def get_metrics(self, is_train: bool = False):
+        return {"loss": DistLoss()}
+
+    def update_metric(self, batch, outputs, metric):
+        metric.update(outputs[0])
+
+    # ---------------------------------------------------------------------------------------- sampling (inference glue)
+    @torch.no_grad()
+    def edm_sampler_loop(self, x, y, steps: Optional[int] = None, cfg: float = 1.0, **kwargs):
+        """Heun 2nd-order EDM sampler, fp64 state (model.py:231-297)."""
+        ec = self.edm_config
+        fwd = partial(self.dit.forward, cfg=cfg) if cfg > 1.0 else self.dit.forward
+        n = ec.num_steps if steps is None else steps
+        idx = torch.arange(n, dtype=torch.float64, device=x.device)
+        inv_rho = 1 / ec.rho
+        t_steps = (ec.sigma_max ** inv_rho + idx / (n - 1) * (ec.sigma_min ** inv_rho - ec.sigma_max ** inv_rho)) ** ec.rho
+        t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
+        x_next = x.to(torch.float64) * t_steps[0]
+        for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+            x_cur = x_next
+            gamma = min(ec.S_churn / n, np.sqrt(2) - 1) if ec.S_min <= t_cur <= ec.S_max else 0
+            t_hat = torch.as_tensor(t_cur + gamma * t_cur)
+            x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * ec.S_noise * self.randn_like(x_cur)
+            den = self.model_forward_wrapper(x_hat.to(torch.float32), t_hat.to(torch.float32), y, fwd, mask_ratio=0, **kwargs)["sample"].to(torch.float64)
+            d_cur = (x_hat - den) / t_hat
+            x_next = x_hat + (t_next - t_hat) * d_cur
+            if i < n - 1:
+                den = self.model_forward_wrapper(x_next.to(torch.float32), t_next.to(torch.float32), y, fwd, mask_ratio=0, **kwargs)["sample"].to(torch.float64)
+                d_prime = (x_next - den) / t_next
+                x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+        return x_next.to(torch.float32)
+
+    @torch.no_grad()
+    def generate(self, prompt: Optional[list] = None, tokenized_prompts=None, attention_mask=None, guidance_scale: float = 5.0,
+                 num_inference_steps: int = 30, seed: Optional[int] = None, return_only_latents: bool = False, **kwargs):
+        """tokenise -> text encoder -> EDM sampler on the HIP DiT -> VAE decode (model.py:299-353)."""
+        assert prompt or tokenized_prompts is not None, "Must provide either prompt or tokenized prompts"
+        device = next(self.dit.parameters()).device
+        gen = torch.Generator(device=device)
+        if seed:
+            gen = gen.manual_seed(seed)
+        if tokenized_prompts is None:
+            out = self.tokenizer.tokenize(prompt)
+            tokenized_prompts = out["input_ids"]
+            attention_mask = out.get("attention_mask")
+        emb = self.text_encoder.encode(tokenized_prompts.to(device),
+                                       attention_mask=attention_mask.to(device) if attention_mask is not None else None)[0]
+        latents = torch.randn((len(emb), self.dit.in_channels, self.latent_res, self.latent_res), device=device, generator=gen)
+        latents = self.edm_sampler_loop(latents, emb, num_inference_steps, cfg=guidance_scale)
+        if return_only_latents:
+            return latents
+        image = self.vae.decode((latents / self.latent_scale).to(DATA_TYPES[self.dtype])).sample
+        return (image / 2 + 0.5).clamp(0, 1).float().detach()
+
+
+def _edm_forward(model: LatentDiffusion, anchor, x, y, rnd, eps, mnoise, mask_ratio):
+    """Forward half of the fused training step.  Returns (loss scalar tensor, tape, dtok_f32)."""
+    dit = model.dit
+    eng = dit._engine
+    L = hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ec = model.edm_config
+    B, C, H, W = x.shape
+    dev = x.device
+    xn = torch.empty_like(x)
+    sigma, cin, cnoise = (torch.empty(B, device=dev) for _ in range(3))
+    hip.check(L.md_edm_prepare(x.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn.data_ptr(), sigma.data_ptr(), cin.data_ptr(),
+                               cnoise.data_ptr(), B, C * H * W, ec.P_mean, ec.P_std, ec.sigma_data, st), "md_edm_prepare")
+    tape = eng.forward(xn, cnoise, y, mask_ratio=mask_ratio, mask_noise=mnoise, in_scale=cin)
+    lps = torch.empty(B, device=dev)
+    loss = torch.empty(1, device=dev)
+    dtok = torch.empty(B * tape.Tk, dit.config.patch_vec, device=dev)
+    hip.check(L.md_edm_loss(tape.out_tok.data_ptr(), None if tape.keep_rows is None else tape.keep_rows.data_ptr(),
+                            xn.data_ptr(), x.data_ptr(), sigma.data_ptr(), lps.data_ptr(), loss.data_ptr(), dtok.data_ptr(), B,
+                            tape.Tk, C, H, W, dit.patch_size, ec.sigma_data, st), "md_edm_loss")
+    tape.loss_per_sample = lps
+    return loss.reshape(()), tape, dtok
+
+
+class _EDMLossFunction(torch.autograd.Function):
+    """loss = EDM(x, y) as one autograd node; backward runs the engine's hand-written backward and accumulates the
+    parameter gradients straight into the flat fp32 grad buffer (the .grad views)."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, x, y, rnd, eps, mnoise, mask_ratio):
+        loss, tape, dtok = _edm_forward(model, anchor, x, y, rnd, eps, mnoise, mask_ratio)
+        ctx.model, ctx.tape, ctx.dtok = model, tape, dtok
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model, tape, dtok = ctx.model, ctx.tape, ctx.dtok
+        dit = model.dit
+        dit.attach_grads()
+        g = gloss.detach().to(torch.float32).contiguous()
+        dtb = torch.empty(dtok.shape, device=dtok.device, dtype=torch.bfloat16)
+        hip.check(hip.lib().md_cast_f32_bf16(dtok.data_ptr(), dtb.data_ptr(), dtok.numel(), g.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "md_cast_f32_bf16")
+        dit._engine.backward(tape, dtb)
+        ctx.tape = ctx.dtok = None
+        return None, torch.zeros_like(dit._grad_anchor), None, None, None, None, None, None
+
+
+class _FrozenStub(nn.Module):
+    """Placeholder for the frozen SDXL-VAE / text encoder when their libraries (diffusers / open_clip) are absent:
+    enough for training on precomputed latents (train.py asserts precomputed_latents), loud on any real use."""
+
+    def __init__(self, what: str, scaling_factor: float = 0.13025):
+        super().__init__()
+        self.what = what
+        self.config = SimpleNamespace(scaling_factor=scaling_factor)
+
+    def _fail(self, *a, **k):
+        raise RuntimeError(f"{self.what} is not available in this environment (library not installed); "
+                           "only precomputed-latent training is possible")
+
+    encode = decode = forward = tokenize = _fail
+
+
+def create_latent_diffusion(vae_name: str = "stabilityai/stable-diffusion-xl-base-1.0",
+                            text_encoder_name: str = "openclip:hf-hub:apple/DFN5B-CLIP-ViT-H-14-378",
+                            dit_arch: str = "MicroDiT_XL_2", latent_res: int = 32, in_channels: int = 4,
+                            pos_interp_scale: float = 1.0, dtype: str = "bfloat16", precomputed_latents: bool = True,
+                            p_mean: float = -0.6, p_std: float = 1.2, train_mask_ratio: float = 0.0) -> LatentDiffusion:
+    """Same signature and behaviour as the reference factory (model.py:356-405); the DiT comes from this package's
+    zoo; the frozen VAE / text encoder are loaded through diffusers / open_clip when those are installed."""
+    s, d = text_encoder_embedding_format(text_encoder_name)
+    dit = getattr(model_zoo, dit_arch)(input_size=latent_res, caption_channels=d, pos_interp_scale=pos_interp_scale,
+                                       in_channels=in_channels)
+    vae = text_encoder = tokenizer = None
+    try:
+        from diffusers import AutoencoderKL  # type: ignore
+        vae = AutoencoderKL.from_pretrained(vae_name, subfolder=None if vae_name == "ostris/vae-kl-f8-d16" else "vae",
+                                            torch_dtype=DATA_TYPES[dtype])
+    except Exception:
+        vae = _FrozenStub(f"VAE '{vae_name}'")
+    try:
+        from .text import UniversalTextEncoder, UniversalTokenizer  # optional, needs open_clip / transformers weights
+        text_encoder = UniversalTextEncoder(text_encoder_name, dtype=dtype, pretrained=True)
+        tokenizer = UniversalTokenizer(text_encoder_name)
+    except Exception:
+        text_encoder = _FrozenStub(f"text encoder '{text_encoder_name}'")
+        tokenizer = _FrozenStub(f"tokenizer '{text_encoder_name}'")
+    return LatentDiffusion(dit=dit, vae=vae, text_encoder=text_encoder, tokenizer=tokenizer,
+                           precomputed_latents=precomputed_latents, dtype=dtype, latent_res=latent_res, p_mean=p_mean,
+                           p_std=p_std, train_mask_ratio=train_mask_ratio)
