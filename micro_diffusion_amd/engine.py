@@ -50,6 +50,7 @@ class DiTEngine:
         self.dev = next(iter(params.values())).device
         self.L = hip.lib()
         self.wgrad_target_blocks = 768
+        self.gemm_profile = None
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
@@ -65,7 +66,14 @@ class DiTEngine:
         a = hip.GemmArgs()
         for k, v in kw.items():
             setattr(a, k, v)
+        prof = self.gemm_profile
+        if prof is not None:      # per-launch HIP events on the launch stream (bench.py roofline leg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.check(self.L.md_gemm_bf16(byref(a), self._st()), "md_gemm_bf16")
+        if prof is not None:
+            e1.record()
+            prof.append((e0, e1, 2.0 * a.M * a.N * a.K * a.batch, (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit)))
 
     def lin_fwd(self, x, wname, out, M, N, K, *, ldx=None, ldc=None, mode=hip.EPI_STORE_BF16, act=0, res=None,
                 gate=None, ldg=0, rps=0, C2=None, ldc2=0, xoff=0, ooff=0, bias=True):
@@ -533,10 +541,12 @@ class DiTEngine:
                                        cfg.in_channels, tp.H, tp.W, cfg.patch_size, self._st()), "unpatchify")
         return img
 
-    def backward(self, tp: Tape, dtok: torch.Tensor) -> None:
+    def backward(self, tp: Tape, dtok: torch.Tensor, on_segment=None) -> None:
         """dtok: bf16 [B*Tk, p*p*C] grad of the network output for the kept tokens.  Accumulates every parameter
-        gradient into the fp32 grad buffers (self.G)."""
+        gradient into the fp32 grad buffers (self.G).  `on_segment(prefix)` is called as soon as every kernel that
+        writes the gradients of the parameters under `prefix` has been enqueued (data-parallel bucket hand-off)."""
         cfg, L, st = self.cfg, self.L, self._st()
+        seg = on_segment if on_segment is not None else (lambda name: None)
         B, T, Tk, Lc = tp.B, tp.T, tp.Tk, tp.Lc
         D, Dm, pv = cfg.dim, cfg.patch_mixer_dim, cfg.patch_vec
         Mc = B * Lc
@@ -555,9 +565,11 @@ class DiTEngine:
         self.ln_bwd(af, dxf, dx, accumulate=False, wname="final_layer.norm_final", dscale=dfm.data_ptr() + 4 * D,
                     dshift=dfm.data_ptr(), ldg=2 * D)
         self._adaln_bwd("final_layer.adaLN_modulation.1", dfm, B, 2 * D, gc, dgc)
+        seg("final_layer")
         # ---- backbone
         for bp, bt in zip(reversed(self.backbone), reversed(tp.blocks)):
             self._block_bwd(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc)
+            seg(bp.name)
         # ---- mixer -> backbone projection
         if cfg.use_patch_mixer and cfg.has_maps:
             self.lin_wgrad(dx, tp.xout_ln, "patch_mixer_map_xout.1", B * Tk, D, Dm)
@@ -578,6 +590,7 @@ class DiTEngine:
         dym_f32 = self.zeros(Mc, Dm) if has_maps else dy2_f32
         for bp, bt in zip(reversed(self.mixer), reversed(tp.mixer)):
             self._block_bwd(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc)
+            seg(bp.name)
         # ---- map_xin / patch embedding
         if has_maps:
             self.lin_wgrad(dx, tp.xin_ln, "patch_mixer_map_xin.1", B * T, Dm, D)
@@ -640,3 +653,4 @@ class DiTEngine:
         self.ln_bwd(a, dxn1, dy, accumulate=True, wname="y_emb_preprocess.norm1")
         # ---- caption projection (inputs need no grad)
         self._mlp_norm_bwd("y_embedder.y_proj", tp.yproj, dy, Mc, tp.ycap.shape[1], Lc, need_dx=False)
+        seg("rest")

@@ -249,7 +249,7 @@ class _EDMLossFunction(torch.autograd.Function):
         dtb = torch.empty(dtok.shape, device=dtok.device, dtype=torch.bfloat16)
         hip.check(hip.lib().md_cast_f32_bf16(dtok.data_ptr(), dtb.data_ptr(), dtok.numel(), g.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream), "md_cast_f32_bf16")
-        dit._engine.backward(tape, dtb)
+        dit._engine.backward(tape, dtb, on_segment=getattr(dit, "_on_segment", None))
         ctx.tape = ctx.dtok = None
         return None, torch.zeros_like(dit._grad_anchor), None, None, None, None, None, None
 

@@ -1,0 +1,208 @@
+"""Training-step runtime for the MI355X MicroDiT path: what Composer's Trainer + FSDP + GradientClipping +
+torch.optim.AdamW + the LR scheduler do around `LatentDiffusion.forward` in the reference (train.py:14-123,
+configs/*.yaml), re-designed for one process per GPU with RCCL over xGMI:
+
+  * the per-rank batch (global_batch / world_size, train.py:50) is split into microbatches of
+    `device_train_microbatch_size` (yaml trainer.device_train_microbatch_size); each microbatch loss is scaled by
+    n_micro / n_rank_batch before backward (Composer semantics); gradients accumulate in
+    the flat fp32 buffer;
+  * data parallelism = gradient averaging (numerically the reference's FSDP SHARD_GRAD_OP, yaml trainer.fsdp_config):
+    during the LAST microbatch's backward each finished segment (final layer, one DiT block, ...) of the flat
+    gradient buffer is all-reduced asynchronously — RCCL runs on its own stream and overlaps the remaining
+    backward kernels; no other collective exists on the data path;
+  * after the last bucket: one fused pass computes ||g||, one fused pass clips (coef from the device-side norm, no
+    host sync), applies AdamW, re-emits the bf16 shadow weights and zeroes the gradients.
+"""
+from __future__ import annotations
+
+import math
+import re
+import time
+from ctypes import byref
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+
+def parse_batches(v) -> int:
+    """'2500ba' -> 2500 (Composer time strings; only batch units appear in configs/*.yaml)."""
+    if isinstance(v, (int, float)):
+        return int(v)
+    m = re.fullmatch(r"\s*(\d+)\s*ba\s*", str(v))
+    if not m:
+        raise ValueError(f"unsupported duration '{v}' (only '<N>ba' is used by the MicroDiT configs)")
+    return int(m.group(1))
+
+
+class LRSchedule:
+    """Composer schedulers named in configs/*.yaml, as multiplicative factors of the base LR, stepped once per batch
+    (SURVEY.md Appendix C.3 — Composer source is not available offline, formulas per its documentation):
+      CosineAnnealingWithWarmupScheduler(t_warmup, alpha_f), ConstantScheduler(alpha),
+      ConstantWithWarmupScheduler(t_warmup, alpha)."""
+
+    def __init__(self, kind: str, t_warmup=0, t_max=1, alpha_f: float = 0.0, alpha: float = 1.0):
+        self.kind, self.t_warmup, self.t_max = kind, parse_batches(t_warmup), parse_batches(t_max)
+        self.alpha_f, self.alpha = alpha_f, alpha
+
+    @staticmethod
+    def from_target(target: str, t_max, **kw) -> "LRSchedule":
+        name = target.split(".")[-1]
+        kinds = {"CosineAnnealingWithWarmupScheduler": "cosine_with_warmup", "ConstantScheduler": "constant",
+                 "ConstantWithWarmupScheduler": "constant_with_warmup"}
+        if name not in kinds:
+            raise ValueError(f"scheduler {target} not supported")
+        kw = {k: v for k, v in kw.items() if k in ("t_warmup", "alpha_f", "alpha")}
+        return LRSchedule(kinds[name], t_max=t_max, **kw)
+
+    def factor(self, step: int) -> float:
+        """`step` = optimiser steps already taken (the first batch trains at factor(0))."""
+        if self.kind == "constant":
+            return self.alpha
+        if self.kind == "constant_with_warmup":
+            return self.alpha * min(1.0, step / self.t_warmup) if self.t_warmup > 0 else self.alpha
+        if step < self.t_warmup:
+            return step / self.t_warmup
+        frac = min(1.0, (step - self.t_warmup) / max(1, self.t_max - self.t_warmup))
+        return self.alpha_f + (1 - self.alpha_f) * 0.5 * (1 + math.cos(math.pi * frac))
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (train.py:39-43) on the DiT's flat buffers, one HIP kernel per step."""
+
+    def __init__(self, dit, lr: float = 2.4e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1):
+        self.dit = dit
+        f = dit.flat_buffers()
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self.m = torch.zeros_like(f["p"])
+        self.v = torch.zeros_like(f["p"])
+        self.sumsq = torch.zeros(1, device=f["p"].device)
+        self.step_count = 0
+
+    def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0) -> None:
+        f = self.dit.flat_buffers()
+        L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
+        self.step_count += 1
+        b1, b2 = self.betas
+        ss = None
+        if max_norm and max_norm > 0:
+            self.sumsq.zero_()
+            hip.check(L.md_sumsq(f["g"].data_ptr(), f["total"], self.sumsq.data_ptr(), st), "md_sumsq")
+            ss = self.sumsq.data_ptr()
+        a = hip.AdamWArgs(f["p"].data_ptr(), f["g"].data_ptr(), self.m.data_ptr(), self.v.data_ptr(), f["s"].data_ptr(), ss,
+                          f["total"], self.lr if lr is None else lr, b1, b2, self.eps, self.weight_decay,
+                          1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale, 1)
+        hip.check(L.md_adamw_step(byref(a), st), "md_adamw_step")
+        self.dit.mark_shadow_fresh()
+
+    def grad_norm(self) -> torch.Tensor:
+        """||g||_2 of the last step before clipping (device scalar; valid after step() with max_norm > 0)."""
+        return self.sumsq.sqrt()
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
+
+
+class GradSync:
+    """Overlapped data-parallel gradient averaging: contiguous segments of the flat fp32 gradient buffer are
+    all-reduced (RCCL, async: RCCL's own stream) as soon as the engine reports their backward as enqueued."""
+
+    def __init__(self, dit, process_group=None):
+        self.dit = dit
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        f = dit.flat_buffers()
+        # segment prefix -> [start, end) in the flat buffer (table order is contiguous per module)
+        import numpy as np
+        self.ranges: Dict[str, List[int]] = {}
+        for spec in dit._table:
+            if spec.buffer:
+                continue
+            top = spec.name.split(".")
+            key = ".".join(top[:2]) if top[0] in ("blocks", "patch_mixer") else ("final_layer" if top[0] == "final_layer" else "rest")
+            o = f["offs"][spec.name]
+            n = ((int(np.prod(spec.shape)) + 63) // 64) * 64
+            r = self.ranges.setdefault(key, [o, o + n])
+            r[0], r[1] = min(r[0], o), max(r[1], o + n)
+        self.pending = []
+        self.active = False
+
+    def on_segment(self, name: str) -> None:
+        if not self.active or self.world == 1:
+            return
+        if name == "rest":
+            for lo, hi in self._rest_ranges():
+                self.pending.append(dist.all_reduce(self.dit.flat_buffers()["g"][lo:hi], group=self.pg, async_op=True))
+            return
+        lo, hi = self.ranges[name]
+        self.pending.append(dist.all_reduce(self.dit.flat_buffers()["g"][lo:hi], group=self.pg, async_op=True))
+
+    def _rest_ranges(self):
+        """'rest' = everything that is not a DiT block or the final layer; not contiguous (front end precedes the
+        mixer, the mixer maps sit between mixer and backbone): reduce the gaps between the block ranges."""
+        total = self.dit.flat_buffers()["total"]
+        taken = sorted(v for k, v in self.ranges.items() if k != "rest")
+        out, cur = [], 0
+        for lo, hi in taken:
+            if lo > cur:
+                out.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < total:
+            out.append((cur, total))
+        return out
+
+    def finish(self) -> None:
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+class Trainer:
+    def __init__(self, model, optimizer: FusedAdamW, schedule: Optional[LRSchedule] = None, clip_norm: float = 0.0,
+                 microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None):
+        self.model, self.opt, self.schedule, self.clip_norm = model, optimizer, schedule, clip_norm
+        self.microbatch_size = microbatch_size
+        self.sync = GradSync(model.dit, process_group)
+        self.world = self.sync.world
+        model.dit._on_segment = self.sync.on_segment
+        self.batches_seen = 0
+        self.log = log
+        self._win: List[tuple] = []
+
+    def train_step(self, batch: dict) -> torch.Tensor:
+        """One optimisation step on this rank's share of the global batch.  Returns the (detached) rank-mean loss."""
+        model = self.model
+        n = batch["image_latents"].shape[0]
+        mb = min(self.microbatch_size, n)
+        starts = list(range(0, n, mb))
+        total = None
+        for i, s in enumerate(starts):
+            part = {k: (v[s:s + mb] if torch.is_tensor(v) and v.shape[0] == n else v) for k, v in batch.items()}
+            self.sync.active = (i == len(starts) - 1)
+            loss = model(part)[0]
+            w = part["image_latents"].shape[0] / n
+            (loss * w).backward()
+            total = loss.detach() * w if total is None else total + loss.detach() * w
+        self.sync.active = False
+        self.sync.finish()
+        fac = self.schedule.factor(self.batches_seen) if self.schedule is not None else 1.0
+        self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world)
+        self.batches_seen += 1
+        return total
+
+    def throughput(self, global_batch: int, window: int = 3) -> Optional[float]:
+        """Composer SpeedMonitor(window_size=3) definition: samples over the last `window` batches / wall time."""
+        torch.cuda.synchronize()
+        self._win.append((time.time(), self.batches_seen))
+        self._win = self._win[-(window + 1):]
+        if len(self._win) < 2:
+            return None
+        (t0, b0), (t1, b1) = self._win[0], self._win[-1]
+        return (b1 - b0) * global_batch / max(t1 - t0, 1e-9)
