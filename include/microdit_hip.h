@@ -56,6 +56,7 @@ typedef struct md_gemm_args {
     int64_t M, N, K;
     int64_t lda, ldb, ldc, ldc2, ldr, ldg, ldaux;
     int64_t sA, sB, sC, sC2, sBias, sAux; /* batch strides (elements) */
+    int64_t sSplit;                       /* STORE_F32 with ksplit > 1: split s writes its partial at C + s * sSplit */
     int64_t rows_per_sample;
     int32_t batch;
     int32_t ksplit;
@@ -66,6 +67,9 @@ typedef struct md_gemm_args {
 } md_gemm_args;
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);
+/* out[b] (+)= sum over the ksplit dense fp32 [M, N] slices a split-K md_gemm_bf16 left in ws (deterministic). */
+int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo, int64_t sOut, int32_t ksplit,
+                     int32_t batch, int32_t accumulate, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- LayerNorm */
 /* y = LN(act(x + pos[row % pos_rows])) * w;  out = y * (1 + scale[row / rows_per_sample]) + shift[...].

@@ -20,6 +20,7 @@
 // (micro_diffusion/models/dit.py:84-89,131-142,224; utils.py:58-61,109-111,172-173,225-233).
 #include "md_common.h"
 #include "../../include/microdit_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -124,80 +125,9 @@ __device__ __forceinline__ float apply_dact(float v, int act) {
     return 1.f;
 }
 
-template <int AKC, int BKC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + TILE_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // ---- XCD-aware tile order (block b runs on XCD b % 8; give each XCD a contiguous tile range) ----
-    const int ntn = (int)((p.N + BN - 1) / BN);
-    const int nwg = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int64_t m0 = (int64_t)(logical / ntn) * BM;
-    const int64_t n0 = (int64_t)(logical % ntn) * BN;
-
-    const int batch = blockIdx.y / p.ksplit;
-    const int split = blockIdx.y % p.ksplit;
-
-    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
-    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
-
-    // split-K range, in whole 64-wide k-tiles
-    const int64_t ntk = (p.K + BKT - 1) / BKT;
-    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
-    const int64_t kbeg = (int64_t)split * tps * BKT;
-    int64_t kend = kbeg + tps * BKT;
-    if (kend > p.K) kend = p.K;
-    const int nt = kbeg < kend ? (int)((kend - kbeg + BKT - 1) / BKT) : 0;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    uint4 ra[4], rb[4];
-    if (nt > 0) {
-        load_tile<AKC>(ra, A, p.lda, m0, p.M, kbeg, kend, tid);
-        load_tile<BKC>(rb, B, p.ldb, n0, p.N, kbeg, kend, tid);
-    }
-    for (int t = 0; t < nt; ++t) {
-        __syncthreads();  // everyone finished reading the previous tile
-        store_tile<AKC>(ra, sA, tid);
-        store_tile<BKC>(rb, sB, tid);
-        __syncthreads();
-        if (t + 1 < nt) {
-            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
-            load_tile<AKC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
-            load_tile<BKC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = load_frag<AKC>(sA, wm * 64 + i * 32, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = load_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ------------------------------------------------------------------ epilogue
+// Shared epilogue: accumulators -> per-wave fp32 LDS slab -> row-contiguous 16-byte global accesses with the fused ops.
+__device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&acc)[2][2], unsigned char* smem, int64_t m0,
+                                              int64_t n0, int batch, int split, int wave, int lane, int wm, int wn) {
     __syncthreads();
     float* slab = reinterpret_cast<float*>(smem) + wave * SLAB_FLOATS;
     const int mode = p.mode;
@@ -271,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] * apply_dact(bf2f(ax[e]), p.act));
                 st_bf16x8(reinterpret_cast<bf16*>(p.C) + (int64_t)batch * p.sC + gr * p.ldc + gc, o);
             } else {
-                float* cp = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.sC + gr * p.ldc + gc;
+                float* cp = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.sC + (int64_t)split * p.sSplit + gr * p.ldc + gc;
                 if (mode == MD_EPI_STORE_F32) {
                     *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -292,7 +222,259 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
     }
 }
 
+template <int AKC, int BKC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile order (block b runs on XCD b % 8; give each XCD a contiguous tile range) ----
+    const int ntn = (int)((p.N + BN - 1) / BN);
+    const int nwg = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t m0 = (int64_t)(logical / ntn) * BM;
+    const int64_t n0 = (int64_t)(logical % ntn) * BN;
+
+    const int batch = blockIdx.y / p.ksplit;
+    const int split = blockIdx.y % p.ksplit;
+
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+
+    // split-K range, in whole 64-wide k-tiles
+    const int64_t ntk = (p.K + BKT - 1) / BKT;
+    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
+    const int64_t kbeg = (int64_t)split * tps * BKT;
+    int64_t kend = kbeg + tps * BKT;
+    if (kend > p.K) kend = p.K;
+    const int nt = kbeg < kend ? (int)((kend - kbeg + BKT - 1) / BKT) : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    if (nt > 0) {
+        load_tile<AKC>(ra, A, p.lda, m0, p.M, kbeg, kend, tid);
+        load_tile<BKC>(rb, B, p.ldb, n0, p.N, kbeg, kend, tid);
+    }
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();  // everyone finished reading the previous tile
+        store_tile<AKC>(ra, sA, tid);
+        store_tile<BKC>(rb, sB, tid);
+        __syncthreads();
+        if (t + 1 < nt) {
+            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
+            load_tile<AKC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
+            load_tile<BKC>(rb, B, p.ldb, n0, p.N, k0, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = load_frag<AKC>(sA, wm * 64 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = load_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    gemm_epilogue(p, acc, smem, m0, n0, batch, split, wave, lane, wm, wn);
+}
+
+// =====================================================================================================================
+// LDS-DMA variant (default): tiles are streamed HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write: the register-staged kernel above is LDS-WRITE bound at 12 waves / CU), two LDS buffers, the loads of
+// tile t+1 stay in flight across the barrier while tile t is multiplied (counted s_waitcnt vmcnt).
+// The LDS image of one wave-instruction is lane-linear (M0 base + lane * 16 B), so bank-conflict avoidance is an XOR
+// swizzle of the 16-byte chunk index applied to the per-lane SOURCE address and again on the fragment reads:
+//   K-contiguous tile  [128 rows][8 chunks]   : physical chunk = chunk ^ ((row >> 1) & 7)   (ds_read_b128, 128-B rows)
+//   K-strided   tile   [ 64 k   ][16 chunks]  : physical chunk = chunk ^ ((k & 3) << 2)     (ds_read_b64_tr_b16, 256-B rows)
+// Out-of-range lanes fetch from a 16-byte zero word instead of being predicated off.
+// =====================================================================================================================
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int DTILE = 16384;                  // bytes per operand tile (both layouts)
+constexpr int DSMEM = 4 * DTILE;              // 2 buffers x (A, B) = 64 KiB -> 2 workgroups / CU
+
+template <int KC>
+__device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t rmax,
+                                         int64_t k0, int64_t kend, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16* src;
+        if (KC) {
+            const int row = wave * 32 + j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int64_t gr = r0 + row, gk = k0 + c * 8;
+            src = (gr < rmax && gk < kend) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
+        } else {
+            const int kk = wave * 16 + j * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((kk & 3) << 2);
+            const int64_t gk = k0 + kk, gr = r0 + c * 8;
+            src = (gr < rmax && gk < kend) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
+        }
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(s + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+}
+
+// Fragment reads as inline asm: hipcc would otherwise put a full s_waitcnt vmcnt(0) in front of every LDS read
+// while an LDS-DMA is pending and so drain the prefetch of the next tile.  The caller waits lgkmcnt(0) itself.
+__device__ __forceinline__ bf16x8 asm_read_b128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void asm_read_tr2(unsigned addr, bf16x4& lo, bf16x4& hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+}
+
+template <int KC>
+__device__ __forceinline__ bf16x8 dma_frag(unsigned sbase, int row0, int ks, int lane) {
+    if (KC) {
+        const int row = row0 + (lane & 31);
+        const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+        return asm_read_b128(sbase + row * 128 + c * 16);
+    } else {
+        const int li = lane & 15;
+        const int col = row0 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+        const int kk = ks * 16 + (lane >> 5) * 8 + (li >> 2);
+        const int pc = (col >> 3) ^ ((kk & 3) << 2);
+        bf16x4 lo, hi;
+        asm_read_tr2(sbase + kk * 256 + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);   // hi: rows kk + 4 (same swizzle)
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(md_gemm_args p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[DSMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntn = (int)((p.N + BN - 1) / BN);
+    const int nwg = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t m0 = (int64_t)(logical / ntn) * BM;
+    const int64_t n0 = (int64_t)(logical % ntn) * BN;
+    const int batch = blockIdx.y / p.ksplit;
+    const int split = blockIdx.y % p.ksplit;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+    const int64_t ntk = (p.K + BKT - 1) / BKT;
+    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
+    const int64_t kbeg = (int64_t)split * tps * BKT;
+    int64_t kend = kbeg + tps * BKT;
+    if (kend > p.K) kend = p.K;
+    const int nt = kbeg < kend ? (int)((kend - kbeg + BKT - 1) / BKT) : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;   // LDS byte address of the staging area
+    if (nt > 0) {
+        dma_tile<AKC>(smem, A, p.lda, m0, p.M, kbeg, kend, wave, lane);
+        dma_tile<BKC>(smem + DTILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    }
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
+            unsigned char* nb = smem + (cur ^ 1) * 2 * DTILE;
+            dma_tile<AKC>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
+            dma_tile<BKC>(nb + DTILE, B, p.ldb, n0, p.N, k0, kend, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                           // ... and every other wave's part of tile t
+        const unsigned sA = lds0 + cur * 2 * DTILE, sB = sA + DTILE;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = dma_frag<AKC>(sA, wm * 64 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();                           // buffer `cur` is free for the DMA of tile t+2
+    }
+    gemm_epilogue(p, acc, smem, m0, n0, batch, split, wave, lane, wm, wn);
+}
+
+// out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
+                                                            int64_t sOut, int ksplit, int batch, int accumulate) {
+    const int64_t n4 = N / 4, per = M * n4, total = per * batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per, r = i % per, m = r / n4, c = (r % n4) * 4;
+        const float* src = ws + ((b * ksplit) * M + m) * N + c;
+        float4 acc = *reinterpret_cast<const float4*>(src);
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * M * N);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float* dst = out + b * sOut + m * ldo + c;
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(dst);
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dst) = acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo, int64_t sOut, int32_t ksplit,
+                                int32_t batch, int32_t accumulate, hipStream_t stream) {
+    if (!ws || !out || M <= 0 || N <= 0 || N % 4 || ldo % 4 || ksplit <= 0 || batch <= 0) return MD_BAD_ARG;
+    int64_t grid = (M * (N / 4) * batch + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, M, N, ldo, sOut, ksplit, batch,
+                       accumulate);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if (!a || !a->A || !a->B || !a->C) return MD_BAD_ARG;
@@ -305,20 +487,28 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if ((a->mode == MD_EPI_STORE_BF16 || a->mode == MD_EPI_RESIDUAL || a->mode == MD_EPI_DACT) ? (a->ldc % 8) : (a->ldc % 4))
         return MD_BAD_ARG;
     if (a->C2 && a->ldc2 % 8) return MD_BAD_ARG;
-    if (a->ksplit > 1 && a->mode != MD_EPI_ATOMIC_F32) return MD_BAD_ARG;
+    // split-K: either atomics into C, or every split stores its own fp32 slice (C + split * sSplit) for md_splitk_reduce
+    if (a->ksplit > 1 && !(a->mode == MD_EPI_ATOMIC_F32 || (a->mode == MD_EPI_STORE_F32 && a->sSplit > 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
     const int64_t tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
     dim3 block(256, 1, 1);
-    if (a->a_kcontig && a->b_kcontig)
-        hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, block, 0, stream, *a);
-    else if (a->a_kcontig && !a->b_kcontig)
-        hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, block, 0, stream, *a);
-    else if (!a->a_kcontig && a->b_kcontig)
-        hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, block, 0, stream, *a);
-    else
-        hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, block, 0, stream, *a);
+    // Variant choice (measured on MI355X in the XL/2 shape mix, profiles/r1_gemm_variants.txt): the LDS-DMA kernel wins
+    // for K >= 1024 with at least one K-contiguous operand (+10-20 %); short-K (768) and the TN weight-gradient
+    // shapes run faster register-staged at 3 workgroups / CU.  MD_GEMM_REGSTAGE / MD_GEMM_DMA force one variant (A/B).
+    static const bool force_regs = getenv("MD_GEMM_REGSTAGE") != nullptr;
+    static const bool force_dma = getenv("MD_GEMM_DMA") != nullptr;
+    const bool use_regs = force_regs || (!force_dma && ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024));
+#define LAUNCH(KERN)                                                                       \
+    do {                                                                                   \
+        if (a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<1, 1>), grid, block, 0, stream, *a);       \
+        else if (a->a_kcontig && !a->b_kcontig) hipLaunchKernelGGL((KERN<1, 0>), grid, block, 0, stream, *a); \
+        else if (!a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<0, 1>), grid, block, 0, stream, *a); \
+        else hipLaunchKernelGGL((KERN<0, 0>), grid, block, 0, stream, *a);                                     \
+    } while (0)
+    if (use_regs) LAUNCH(gemm_bf16_kernel); else LAUNCH(gemm_bf16_dma_kernel);
+#undef LAUNCH
     MD_LAUNCH_CHECK();
     return 0;
 }

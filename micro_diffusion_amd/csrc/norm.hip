@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p) {
 
 // grid = (row chunks per sample, samples); every block stays inside one sample so the per-sample column sums
 // (dscale / dshift) are reduced in registers + LDS and published with one atomicAdd per column per block.
-template <int NCH>
+// ACT = false is the hot instantiation (no pre-norm activation): it keeps ~100 VGPRs -> 4-5 waves / SIMD.
+template <int NCH, bool ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_args b) {
     __shared__ float red[4][64 * 8 * NCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
     const bf16* sc = p.scale ? reinterpret_cast<const bf16*>(p.scale) + smp * p.ldmod : nullptr;
     const bool want_cols = b.dscale || b.dshift || b.dw;
 
-    float accS[NCH][8], accD[NCH][8], wk[NCH][8], mk[NCH][8];
+    float accS[NCH][8], accD[NCH][8], wm[NCH][8];   // wm = w * (1 + scale): d(out)/d(xhat) per column
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = lane * 8 + j * 512;
@@ -142,14 +143,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
         for (int e = 0; e < 8; ++e) {
             accS[j][e] = 0.f;
             accD[j][e] = 0.f;
-            wk[j][e] = (w && c < p.C) ? w[c + e] : 1.f;
-            mk[j][e] = (sc && c < p.C) ? 1.f + bf2f(scv[e]) : 1.f;
+            const float wv = (w && c < p.C) ? w[c + e] : 1.f;
+            const float mv = (sc && c < p.C) ? 1.f + bf2f(scv[e]) : 1.f;
+            wm[j][e] = wv * mv;
         }
     }
     for (int64_t lr = r0 + wave; lr < r1; lr += 4) {
         const int64_t row = smp * rps + lr;
-        float v[NCH][8], raw[NCH][8];
-        load_row<NCH, true>(p, row, lane, v, raw);
+        float v[NCH][8], raw[ACT ? NCH : 1][8];
+        if (ACT) {
+            float (&rw)[NCH][8] = reinterpret_cast<float (&)[NCH][8]>(raw);
+            load_row<NCH, true>(p, row, lane, v, rw);
+        } else {
+            float dummy[NCH][8];
+            load_row<NCH, false>(p, row, lane, v, dummy);
+        }
         const float mean = reinterpret_cast<const float*>(p.mean)[row];
         const float rstd = reinterpret_cast<const float*>(p.rstd)[row];
         const bf16* dzr = reinterpret_cast<const bf16*>(b.dz) + row * b.lddz;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
                     v[j][e] = xh;
                     accS[j][e] += dz * xh;
                     accD[j][e] += dz;
-                    const float gg = dz * mk[j][e] * wk[j][e];
+                    const float gg = dz * wm[j][e];
                     g[j][e] = gg;
                     s1 += gg;
                     s2 += gg * xh;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float d = rstd * (g[j][e] - s1 - v[j][e] * s2);
-                        if (p.act) d *= act_bwd(raw[j][e], p.act);
+                        if (ACT) d *= act_bwd(raw[j][e], p.act);
                         if (b.accumulate) d += bf2f(prev[e]);
                         o[e] = f2bf(d);
                     }
@@ -359,12 +367,13 @@ extern "C" int md_ln_bwd(const md_ln_args* a, const md_ln_bwd_args* b, hipStream
     const int64_t rps = a->rows_per_sample > 0 ? a->rows_per_sample : a->rows;
     if (a->rows % rps) return MD_BAD_ARG;
     dim3 grid((unsigned)((rps + b->rows_per_block - 1) / b->rows_per_block), (unsigned)(a->rows / rps), 1);
-    if (a->C <= 512)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, stream, *a, *b);
-    else if (a->C <= 1024)
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, stream, *a, *b);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, stream, *a, *b);
+#define LNB(N, A) hipLaunchKernelGGL((ln_bwd_kernel<N, A>), grid, dim3(256), 0, stream, *a, *b)
+    if (a->act) {
+        if (a->C <= 512) LNB(1, true); else if (a->C <= 1024) LNB(2, true); else LNB(4, true);
+    } else {
+        if (a->C <= 512) LNB(1, false); else if (a->C <= 1024) LNB(2, false); else LNB(4, false);
+    }
+#undef LNB
     MD_LAUNCH_CHECK();
     return 0;
 }

@@ -51,6 +51,7 @@ class DiTEngine:
         self.L = hip.lib()
         self.wgrad_target_blocks = 768
         self.gemm_profile = None
+        self.ws = torch.empty(64 << 20, device=self.dev, dtype=F32)   # 256 MiB split-K workspace
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
@@ -92,18 +93,34 @@ class DiTEngine:
                    res=_p(res), M=M, N=K, K=N, lda=lddy or N, ldb=K, ldc=K, ldaux=K, ldr=K, batch=1, ksplit=1,
                    a_kcontig=1, b_kcontig=0, mode=mode, act=act, alpha=1.0)
 
-    def _ksplit(self, out_rows, out_cols, contraction):
-        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    def _ksplit(self, out_rows, out_cols, contraction, batch=1):
+        """Split-K factor for GEMMs whose output is too small to fill the chip (weight gradients, skinny dgrads):
+        aim at ~3 workgroups per CU, keep >= 512 contraction elements per split, stay inside the workspace."""
+        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * batch
         ks = max(1, self.wgrad_target_blocks // tiles)
-        return max(1, min(ks, (contraction + 511) // 512))
+        ks = min(ks, max(1, contraction // 512))
+        ks = min(ks, max(1, self.ws.numel() // (out_rows * out_cols * batch)))
+        return max(1, ks)
+
+    def gemm_f32_acc(self, *, out_ptr, M, N, K, ldo, batch=1, sOut=0, accumulate=True, **operands):
+        """fp32 C (+)= A B^T with automatic split-K: partial products go to a workspace as dense fp32 slices and are
+        summed by md_splitk_reduce (deterministic; float atomics measured 4-10x slower on this shape class)."""
+        ks = self._ksplit(M, N, K, batch)
+        if ks == 1:
+            self._gemm(C=out_ptr, M=M, N=N, K=K, ldc=ldo, sC=sOut, batch=batch, ksplit=1,
+                       mode=hip.EPI_ACCUM_F32 if accumulate else hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
+            return
+        self._gemm(C=self.ws.data_ptr(), M=M, N=N, K=K, ldc=N, sC=ks * M * N, sSplit=M * N, batch=batch, ksplit=ks,
+                   mode=hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
+        hip.check(self.L.md_splitk_reduce(self.ws.data_ptr(), out_ptr, M, N, ldo, sOut, ks, batch, 1 if accumulate else 0,
+                                          self._st()), "md_splitk_reduce")
 
     def lin_wgrad(self, dy, x, wname, M, N, K, *, lddy=None, ldx=None, dyoff=0, xoff=0, bias_from=None):
-        """grad W[N,K] += dy[M,N]^T @ x[M,K]  (both operands K-strided, split-K atomics into the fp32 grad);
+        """grad W[N,K] += dy[M,N]^T @ x[M,K]  (both operands K-strided; split-K over the token dimension);
         grad b[N] += column sums of dy."""
-        ks = self._ksplit(N, K, M)
-        self._gemm(A=dy.data_ptr() + 2 * dyoff, B=x.data_ptr() + 2 * xoff, C=self.G[wname + ".weight"].data_ptr(), M=N, N=K,
-                   K=M, lda=lddy or N, ldb=ldx or K, ldc=K, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
-                   mode=hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        self.gemm_f32_acc(out_ptr=self.G[wname + ".weight"].data_ptr(), M=N, N=K, K=M, ldo=K,
+                          A=dy.data_ptr() + 2 * dyoff, B=x.data_ptr() + 2 * xoff, lda=lddy or N, ldb=ldx or K,
+                          a_kcontig=0, b_kcontig=0)
         gb = self.G.get(wname + ".bias")
         if gb is not None:
             src = dy if bias_from is None else bias_from
@@ -118,9 +135,18 @@ class DiTEngine:
     def ln_fwd(self, a):
         hip.check(self.L.md_ln_fwd(byref(a), self._st()), "md_ln_fwd")
 
+    @staticmethod
+    def _rows_per_block(rows, rps):
+        """Rows of one sample per workgroup for the column-reducing backward kernels: aim at >= 2048 workgroups
+        (4 waves each) without dropping below 4 rows per workgroup (one per wave)."""
+        rpb = 64
+        while rpb > 4 and (rows + rpb - 1) // rpb < 2048:
+            rpb //= 2
+        return int(max(1, min(rpb, rps)))
+
     def ln_bwd(self, a, dz, dx, *, accumulate, wname=None, dscale=None, dshift=None, ldg=0, rps_total=None):
         rps = a.rows_per_sample if a.rows_per_sample > 0 else a.rows
-        rpb = 64 if rps >= 64 else int(rps)
+        rpb = self._rows_per_block(a.rows, rps)
         b = hip.LnBwdArgs(dz.data_ptr(), _p(dx), dscale, dshift, _p(self.G[wname + ".weight"]) if wname else None,
                           a.C, a.C, ldg, rpb, 1 if accumulate else 0)
         hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd")
@@ -265,7 +291,7 @@ class DiTEngine:
         mp = t.mod.data_ptr()
         dmod = self.zeros(B, 6 * d)          # fp32 grads of (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp)
         dmp = dmod.data_ptr()
-        rpb = 64 if S >= 64 else S
+        rpb = self._rows_per_block(M, S)
         # ---------------- feed-forward branch
         dbr3 = self.empty(M, d)
         hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, 6 * d, dbr3.data_ptr(), dmp + 4 * 5 * d, 6 * d,
@@ -290,19 +316,17 @@ class DiTEngine:
             dgval = self.empty(E, Bk, dtype=F32)
             hip.check(L.md_moe_combine_bwd(dbr3.data_ptr(), t.h2.data_ptr(), t.rowidx.data_ptr(), t.gval.data_ptr(),
                                            dh2.data_ptr(), dgval.data_ptr(), E * Bk, d, st), "combine_bwd")
-            ks = self._ksplit(f, d, Bk)
-            emode = hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32
             # dW2[e][f, d] += hact[e]^T dh2[e]
-            self._gemm(A=t.hact.data_ptr(), B=dh2.data_ptr(), C=g2.data_ptr(), M=f, N=d, K=Bk, lda=f, ldb=d, ldc=d, sA=Bk * f,
-                       sB=Bk * d, sC=f * d, batch=E, ksplit=ks, a_kcontig=0, b_kcontig=0, mode=emode, act=0, alpha=1.0)
+            self.gemm_f32_acc(out_ptr=g2.data_ptr(), M=f, N=d, K=Bk, ldo=d, batch=E, sOut=f * d, A=t.hact.data_ptr(),
+                              B=dh2.data_ptr(), lda=f, ldb=d, sA=Bk * f, sB=Bk * d, a_kcontig=0, b_kcontig=0)
             # dhpre = (dh2 @ W2[e]^T) * gelu'(hpre)
             dhpre = self.empty(E, Bk, f)
             self._gemm(A=dh2.data_ptr(), B=w2.data_ptr(), C=dhpre.data_ptr(), aux=t.hpre.data_ptr(), M=Bk, N=f, K=d, lda=d,
                        ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d, sC=Bk * f, sAux=Bk * f, batch=E, ksplit=1, a_kcontig=1,
                        b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, alpha=1.0)
             # dW1[e][d, f] += xin[e]^T dhpre[e]
-            self._gemm(A=t.xin.data_ptr(), B=dhpre.data_ptr(), C=g1.data_ptr(), M=d, N=f, K=Bk, lda=d, ldb=f, ldc=f,
-                       sA=Bk * d, sB=Bk * f, sC=d * f, batch=E, ksplit=ks, a_kcontig=0, b_kcontig=0, mode=emode, act=0, alpha=1.0)
+            self.gemm_f32_acc(out_ptr=g1.data_ptr(), M=d, N=f, K=Bk, ldo=f, batch=E, sOut=d * f, A=t.xin.data_ptr(),
+                              B=dhpre.data_ptr(), lda=d, ldb=f, sA=Bk * d, sB=Bk * f, a_kcontig=0, b_kcontig=0)
             # dxin = dhpre @ W1[e]^T
             dxin = self.empty(E, Bk, d)
             self._gemm(A=dhpre.data_ptr(), B=w1.data_ptr(), C=dxin.data_ptr(), M=Bk, N=d, K=f, lda=f, ldb=f, ldc=d, sA=Bk * f,
@@ -331,9 +355,8 @@ class DiTEngine:
         self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)
         self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
         # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens
-        self._gemm(A=dkv.data_ptr(), B=self.S[n + ".cross_attn.kv_linear.weight"].data_ptr(), C=dycond_f32.data_ptr(), M=Mc,
-                   N=d, K=2 * hx, lda=2 * hx, ldb=d, ldc=d, batch=1, ksplit=1, a_kcontig=1, b_kcontig=0,
-                   mode=hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        self.gemm_f32_acc(out_ptr=dycond_f32.data_ptr(), M=Mc, N=d, K=2 * hx, ldo=d, A=dkv.data_ptr(),
+                          B=self.S[n + ".cross_attn.kv_linear.weight"].data_ptr(), lda=2 * hx, ldb=d, a_kcontig=1, b_kcontig=0)
         dxn2 = self.empty(M, d)
         self.lin_dgrad(dq2, n + ".cross_attn.q_linear", dxn2, M, hx, d)
         a2 = self.ln_args(t.x1, n + ".norm2", None, M, d, mean=t.st2[0], rstd=t.st2[1], rps=S)
@@ -356,8 +379,8 @@ class DiTEngine:
         dmod = self.empty(B, N)
         hip.check(self.L.md_cast_f32_bf16(dmod_f32.data_ptr(), dmod.data_ptr(), B * N, None, self._st()), "cast")
         self.lin_wgrad(dmod, gc, wname, B, N, D, bias_from=dmod_f32)
-        self._gemm(A=dmod.data_ptr(), B=self.S[wname + ".weight"].data_ptr(), C=dgc_f32.data_ptr(), M=B, N=D, K=N, lda=N,
-                   ldb=D, ldc=D, batch=1, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        self.gemm_f32_acc(out_ptr=dgc_f32.data_ptr(), M=B, N=D, K=N, ldo=D, A=dmod.data_ptr(),
+                          B=self.S[wname + ".weight"].data_ptr(), lda=N, ldb=D, a_kcontig=1, b_kcontig=0)
 
     # ------------------------------------------------------------------------------------------ small MLPs (Mlp with norm)
     def _mlp_norm_fwd(self, pre, xin, rows, cin, rps, res=None):
@@ -602,10 +625,8 @@ class DiTEngine:
             self.ln_bwd(a, dln, dtok_e, accumulate=False, wname="patch_mixer_map_xin.0")
         else:
             dtok_e = dx
-        ks = self._ksplit(D, pv, B * T)
-        self._gemm(A=dtok_e.data_ptr(), B=tp.patches.data_ptr(), C=self.G["x_embedder.proj.weight"].data_ptr(), M=D, N=pv,
-                   K=B * T, lda=D, ldb=pv, ldc=pv, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
-                   mode=hip.EPI_ATOMIC_F32 if ks > 1 else hip.EPI_ACCUM_F32, act=0, alpha=1.0)
+        self.gemm_f32_acc(out_ptr=self.G["x_embedder.proj.weight"].data_ptr(), M=D, N=pv, K=B * T, ldo=pv,
+                          A=dtok_e.data_ptr(), B=tp.patches.data_ptr(), lda=D, ldb=pv, a_kcontig=0, b_kcontig=0)
         hip.check(L.md_colsum(dtok_e.data_ptr(), 0, D, self.G["x_embedder.proj.bias"].data_ptr(), B * T, D, st), "colsum")
         # ---- condition vector: c = temb + pooled ; gc = gelu(c)
         dc = self.empty(B, D)

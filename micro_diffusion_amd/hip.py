@@ -85,7 +85,7 @@ class GemmArgs(Structure):
         ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldc2", c_int64), ("ldr", c_int64),
         ("ldg", c_int64), ("ldaux", c_int64),
         ("sA", c_int64), ("sB", c_int64), ("sC", c_int64), ("sC2", c_int64), ("sBias", c_int64),
-        ("sAux", c_int64),
+        ("sAux", c_int64), ("sSplit", c_int64),
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float),
@@ -166,6 +166,7 @@ class AdamWArgs(Structure):
 
 
 _sig("md_gemm_bf16", POINTER(GemmArgs), P)
+_sig("md_splitk_reduce", P, P, I64, I64, I64, I64, I32, I32, I32, P)
 _sig("md_ln_fwd", POINTER(LnArgs), P)
 _sig("md_ln_bwd", POINTER(LnArgs), POINTER(LnBwdArgs), P)
 _sig("md_qkln_fwd", P, I64, I64, I64, I64, P, F32, P)
@@ -222,7 +223,7 @@ def stream_ptr():
 
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
-         aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, ksplit=1,
+         aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
          stream=None):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
     def ptr(x):
@@ -230,6 +231,6 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
             return None
         return x if isinstance(x, int) else x.data_ptr()
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
-                 M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux,
+                 M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha)
     check(lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr()), "md_gemm_bf16")

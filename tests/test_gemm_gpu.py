@@ -122,3 +122,21 @@ def test_gemm_batched_grouped(hip):
     torch.cuda.synchronize()
     ref = torch.einsum("erd,edf->erf", X.float(), W.float())
     assert (H.float() - ref).abs().max() < 2e-2 * ref.abs().max()
+
+
+def test_gemm_splitk_workspace_reduce(hip):
+    """Split-K through fp32 workspace slices + md_splitk_reduce (the weight-gradient path): TN layout, batched."""
+    dev = "cuda"
+    torch.manual_seed(9)
+    E, R, D, F = 3, 2048, 256, 384
+    X = torch.randn(E, R, D, device=dev).to(torch.bfloat16)       # [rows, d]
+    dH = torch.randn(E, R, F, device=dev).to(torch.bfloat16)      # [rows, f]
+    G = torch.ones(E, D, F, device=dev)                           # accumulate into existing grads
+    ks = 4
+    ws = torch.empty(E * ks * D * F, device=dev)
+    hip.gemm(X, dH, ws, D, F, R, lda=D, ldb=F, ldc=F, a_kcontig=0, b_kcontig=0, mode=hip.EPI_STORE_F32, batch=E,
+             sA=R * D, sB=R * F, sC=ks * D * F, sSplit=D * F, ksplit=ks)
+    hip.check(hip.lib().md_splitk_reduce(ws.data_ptr(), G.data_ptr(), D, F, F, D * F, ks, E, 1, hip.stream_ptr()), "reduce")
+    torch.cuda.synchronize()
+    ref = 1 + torch.einsum("erd,erf->edf", X.float(), dH.float())
+    assert (G - ref).abs().max() < 2e-3 * ref.abs().max()
