@@ -20,6 +20,17 @@ from .engine import DiTEngine
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the fp32 buffers and 128-byte in the bf16 shadow
 
 
+def flat_layout(table):
+    """Offsets (in elements) of every parameter inside the flat buffers: table order, each tensor padded to _ALIGN."""
+    offs, total = {}, 0
+    for spec in table:
+        if spec.buffer:
+            continue
+        offs[spec.name] = total
+        total += ((int(np.prod(spec.shape)) + _ALIGN - 1) // _ALIGN) * _ALIGN
+    return offs, total
+
+
 class _Node(nn.Module):
     """Structural container: exists only so that state_dict() keys mirror the reference module tree."""
     pass
@@ -156,12 +167,7 @@ class DiT(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("micro_diffusion_amd.DiT runs only on an AMD GPU (HIP kernels); call .to('cuda') first. "
                                "There is no CPU fallback.")
-        offs, total = {}, 0
-        for spec in self._table:
-            if spec.buffer:
-                continue
-            offs[spec.name] = total
-            total += ((int(np.prod(spec.shape)) + _ALIGN - 1) // _ALIGN) * _ALIGN
+        offs, total = flat_layout(self._table)
         flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         flat_s = torch.zeros(total, device=dev, dtype=torch.bfloat16)

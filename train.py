@@ -1,0 +1,95 @@
+"""Training entry point with the reference's CLI (reference train.py:14-123, README.md:34-50):
+
+    python train.py --config-path ./configs --config-name res_256_pretrain.yaml exp_name=... model.train_mask_ratio=0.75
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config-path ... (one rank / GPU)
+
+Composer / hydra are replaced by micro_diffusion_amd.{config,trainer}; the model, loss, backward, gradient averaging,
+clipping and AdamW all run as HIP kernels."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from micro_diffusion_amd import config as mdcfg  # noqa: E402
+from micro_diffusion_amd.model import text_encoder_embedding_format  # noqa: E402
+from micro_diffusion_amd.trainer import FusedAdamW, LRSchedule, Trainer, parse_batches  # noqa: E402
+
+
+def train(cfg: dict):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.manual_seed(cfg["seed"])                               # reproducibility.seed_all(cfg.seed)  (train.py:23)
+    assert cfg["model"]["precomputed_latents"], "latents must be precomputed (train.py:25)"
+    model = mdcfg.instantiate(cfg["model"])
+    model.dit.to("cuda")
+    model.train()
+    if cfg["trainer"].get("load_path"):
+        sd = torch.load(cfg["trainer"]["load_path"], map_location="cuda")
+        sd = sd.get("state", {}).get("model", sd)
+        sd = {k[len("dit."):] if k.startswith("dit.") else k: v for k, v in sd.items()}
+        ignore = [k.split("/")[-1] for k in cfg["trainer"].get("load_ignore_keys", [])]
+        sd = {k: v for k, v in sd.items() if not any(k == i.replace("dit.", "") for i in ignore)}
+        model.dit.load_state_dict(sd, strict=bool(cfg["trainer"].get("load_strict_model_weights", True)) and not ignore)
+    ocfg = dict(cfg["optimizer"])
+    ocfg.pop("_target_")
+    opt = FusedAdamW(model.dit, lr=ocfg["lr"], betas=tuple(ocfg.get("betas", (0.9, 0.999))), eps=ocfg.get("eps", 1e-8),
+                     weight_decay=ocfg.get("weight_decay", 0.0))
+    max_ba = parse_batches(cfg["trainer"]["max_duration"])
+    scfg = dict(cfg["scheduler"])
+    sched = LRSchedule.from_target(scfg.pop("_target_"), t_max=max_ba, **scfg)
+    clip = 0.0
+    for name, alg in (cfg.get("algorithms") or {}).items():
+        if name == "gradient_clipping":
+            clip = float(alg["clip_norm"])
+        elif name != "low_precision_layernorm":                    # LP-LayerNorm is the engine's native numerics
+            print(f"Algorithm {name} not supported.")              # same message as the reference (train.py:87-88)
+    seq, emb = text_encoder_embedding_format(cfg["model"]["text_encoder_name"])
+    ds = cfg["dataset"]
+    loader = mdcfg.instantiate(ds["train"], image_size=ds["image_size"], batch_size=ds["train_batch_size"] // world,
+                               cap_seq_size=seq, cap_emb_dim=emb, cap_drop_prob=ds["cap_drop_prob"])
+    trainer = Trainer(model, opt, sched, clip_norm=clip, microbatch_size=int(cfg["trainer"]["device_train_microbatch_size"]))
+    save_every = parse_batches(cfg["trainer"].get("save_interval", "0ba"))
+    folder = cfg["trainer"].get("save_folder")
+    log_every = int(cfg.get("misc", {}).get("log_interval", 10))
+    t_last = time.time()
+    for step, batch in zip(range(max_ba), loader):
+        loss = trainer.train_step(batch)
+        if not torch.isfinite(loss):                               # NaNCatcher (callbacks.py:47-64)
+            raise RuntimeError(f"Train loss contains a NaN at batch {step}")
+        if rank == 0 and (step + 1) % log_every == 0:
+            torch.cuda.synchronize()
+            dt, t_last = time.time() - t_last, time.time()
+            print(json.dumps({"batch": step + 1, "loss": float(loss), "lr": opt.lr * sched.factor(step),
+                              "samples_per_sec": ds["train_batch_size"] * log_every / dt}), flush=True)
+        if rank == 0 and folder and save_every and (step + 1) % save_every == 0:
+            os.makedirs(folder, exist_ok=True)
+            torch.save({"state": {"model": {"dit." + k: v for k, v in model.dit.state_dict().items()}},
+                        "optimizer": opt.state_dict(), "batch": step + 1}, os.path.join(folder, "latest.pt"))
+    return trainer
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config-path", required=True)
+    ap.add_argument("--config-name", required=True)
+    ap.add_argument("overrides", nargs="*")
+    a = ap.parse_args()
+    cfg = mdcfg.load_config(a.config_path, a.config_name, a.overrides)
+    if not cfg:
+        raise ValueError("Config not specified. Please provide --config-path and --config-name, respectively.")
+    train(cfg)
+
+
+if __name__ == "__main__":
+    main()
