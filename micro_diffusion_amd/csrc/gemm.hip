@@ -21,6 +21,7 @@
 #include "md_common.h"
 #include "../../include/microdit_hip.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -126,8 +127,10 @@ __device__ __forceinline__ float apply_dact(float v, int act) {
 }
 
 // Shared epilogue: accumulators -> per-wave fp32 LDS slab -> row-contiguous 16-byte global accesses with the fused ops.
-__device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&acc)[2][2], unsigned char* smem, int64_t m0,
-                                              int64_t n0, int batch, int split, int wave, int lane, int wm, int wn) {
+// (mw0, nw0) = global row / column of this wave's (MI * 32) x 64 output block.
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&acc)[MI][2], unsigned char* smem, int64_t mw0,
+                                              int64_t nw0, int batch, int split, int wave, int lane) {
     __syncthreads();
     float* slab = reinterpret_cast<float*>(smem) + wave * SLAB_FLOATS;
     const int mode = p.mode;
@@ -135,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
     const int erow = lane >> 3;        // 0..7
     const int ecol = (lane & 7) * 8;   // 0..56
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -148,8 +151,8 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int lr = it * 8 + erow;
-            const int64_t gr = m0 + wm * 64 + mi * 32 + lr;
-            const int64_t gc = n0 + wn * 64 + ecol;
+            const int64_t gr = mw0 + mi * 32 + lr;
+            const int64_t gc = nw0 + ecol;
             if (gr >= p.M || gc >= p.N) continue;
             float v[8];
             {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
         }
     }
 
-    gemm_epilogue(p, acc, smem, m0, n0, batch, split, wave, lane, wm, wn);
+    gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, batch, split, wave, lane);
 }
 
 // =====================================================================================================================
@@ -313,12 +316,14 @@ __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void glb_void_t;
 
-constexpr int DTILE = 16384;                  // bytes per operand tile (both layouts)
-constexpr int DSMEM = 4 * DTILE;              // 2 buffers x (A, B) = 64 KiB -> 2 workgroups / CU
-
-template <int KC>
+// Tile geometry is a template parameter: ROWS = rows (or columns) of the operand tile (128 or 256), always 64 deep in K.
+// One wave-instruction moves 1 KiB: 8 rows of a K-contiguous tile, or 512/ROWS rows of a K-strided tile; every wave
+// issues 4 of them per operand per tile for both supported geometries (128^2 x 4 waves, 256^2 x 8 waves).
+template <int KC, int ROWS>
 __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t rmax,
                                          int64_t k0, int64_t kend, int wave, int lane) {
+    constexpr int RPC = 512 / ROWS;       // K-strided: k-rows per 1 KiB chunk (4 or 2)
+    constexpr int LPR = 64 / RPC;         // lanes (16-byte chunks) per k-row (16 or 32)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bf16* src;
@@ -328,8 +333,8 @@ __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restric
             const int64_t gr = r0 + row, gk = k0 + c * 8;
             src = (gr < rmax && gk < kend) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
         } else {
-            const int kk = wave * 16 + j * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ ((kk & 3) << 2);
+            const int kk = (wave * 4 + j) * RPC + lane / LPR;
+            const int c = (lane % LPR) ^ ((kk & 3) << 2);
             const int64_t gk = k0 + kk, gr = r0 + c * 8;
             src = (gr < rmax && gk < kend) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
         }
@@ -344,11 +349,12 @@ __device__ __forceinline__ bf16x8 asm_read_b128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+template <int OFF>
 __device__ __forceinline__ void asm_read_tr2(unsigned addr, bf16x4& lo, bf16x4& hi) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(OFF) : "memory");
 }
 
-template <int KC>
+template <int KC, int ROWS>
 __device__ __forceinline__ bf16x8 dma_frag(unsigned sbase, int row0, int ks, int lane) {
     if (KC) {
         const int row = row0 + (lane & 31);
@@ -360,7 +366,7 @@ __device__ __forceinline__ bf16x8 dma_frag(unsigned sbase, int row0, int ks, int
         const int kk = ks * 16 + (lane >> 5) * 8 + (li >> 2);
         const int pc = (col >> 3) ^ ((kk & 3) << 2);
         bf16x4 lo, hi;
-        asm_read_tr2(sbase + kk * 256 + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);   // hi: rows kk + 4 (same swizzle)
+        asm_read_tr2<4 * ROWS * 2>(sbase + kk * (ROWS * 2) + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);   // hi: k-rows + 4
         bf16x8 f;
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
         f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -368,14 +374,19 @@ __device__ __forceinline__ bf16x8 dma_frag(unsigned sbase, int row0, int ks, int
     }
 }
 
-template <int AKC, int BKC>
-__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(md_gemm_args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[DSMEM];
+// WM x WN waves; every wave owns (MI * 32) x 64 outputs.  TM = WM * MI * 32, TN = WN * 64.
+template <int AKC, int BKC, int WM, int WN, int MI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_args p) {
+    constexpr int TM = WM * MI * 32, TN = WN * 64;
+    constexpr int ATILE = TM * 128, BTILE = TN * 128;          // bytes (64 k x 2 B per row / column)
+    constexpr int BUF = ATILE + BTILE;
+    constexpr int SLAB = WM * WN * SLAB_FLOATS * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 * BUF > SLAB) ? 2 * BUF : SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
-    const int ntn = (int)((p.N + BN - 1) / BN);
+    const int ntn = (int)((p.N + TN - 1) / TN);
     const int nwg = gridDim.x;
     int logical;
     {
@@ -383,8 +394,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(md_gemm_args p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int64_t m0 = (int64_t)(logical / ntn) * BM;
-    const int64_t n0 = (int64_t)(logical % ntn) * BN;
+    const int64_t m0 = (int64_t)(logical / ntn) * TM;
+    const int64_t n0 = (int64_t)(logical % ntn) * TN;
     const int batch = blockIdx.y / p.ksplit;
     const int split = blockIdx.y % p.ksplit;
     const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
@@ -396,9 +407,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(md_gemm_args p) {
     if (kend > p.K) kend = p.K;
     const int nt = kbeg < kend ? (int)((kend - kbeg + BKT - 1) / BKT) : 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -406,40 +417,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(md_gemm_args p) {
 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;   // LDS byte address of the staging area
     if (nt > 0) {
-        dma_tile<AKC>(smem, A, p.lda, m0, p.M, kbeg, kend, wave, lane);
-        dma_tile<BKC>(smem + DTILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+        dma_tile<AKC, TM>(smem, A, p.lda, m0, p.M, kbeg, kend, wave, lane);
+        dma_tile<BKC, TN>(smem + ATILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
     }
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
             const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
-            unsigned char* nb = smem + (cur ^ 1) * 2 * DTILE;
-            dma_tile<AKC>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
-            dma_tile<BKC>(nb + DTILE, B, p.ldb, n0, p.N, k0, kend, wave, lane);
+            unsigned char* nb = smem + (cur ^ 1) * BUF;
+            dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
+            dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                           // ... and every other wave's part of tile t
-        const unsigned sA = lds0 + cur * 2 * DTILE, sB = sA + DTILE;
+        const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
 #pragma unroll
         for (int ks = 0; ks < BKT / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[MI], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = dma_frag<AKC>(sA, wm * 64 + i * 32, ks, lane);
+            for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
+            for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_barrier();                           // buffer `cur` is free for the DMA of tile t+2
     }
-    gemm_epilogue(p, acc, smem, m0, n0, batch, split, wave, lane, wm, wn);
+    gemm_epilogue<MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * 64, batch, split, wave, lane);
 }
 
 // out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
@@ -491,23 +502,35 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if (a->ksplit > 1 && !(a->mode == MD_EPI_ATOMIC_F32 || (a->mode == MD_EPI_STORE_F32 && a->sSplit > 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
-    const int64_t tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    // Variant choice (measured on MI355X in the XL/2 shape mix, profiles/r1_gemm_variants.txt):
+    //  * 256 x 256 LDS-DMA tiles (8 waves) when they fill the chip (>= ~1 tile per CU) — longest prefetch distance,
+    //    half the global->LDS traffic per flop;
+    //  * else 128 x 128: LDS-DMA for K >= 1024 with a K-contiguous operand, register-staged (3 workgroups / CU) for
+    //    short K and the TN weight-gradient shapes.
+    // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
+    static const char* force = getenv("MD_GEMM_VARIANT");
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256
+    const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
+    if (force && force[0] == 'r') variant = 0;
+    else if (force && !strcmp(force, "dma128")) variant = 1;
+    else if (force && !strcmp(force, "dma256")) variant = 2;
+    else if (tiles256 >= 224 && a->K >= 256) variant = 2;
+    else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
+    const int TMv = variant == 2 ? 256 : 128;
+    const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
-    dim3 block(256, 1, 1);
-    // Variant choice (measured on MI355X in the XL/2 shape mix, profiles/r1_gemm_variants.txt): the LDS-DMA kernel wins
-    // for K >= 1024 with at least one K-contiguous operand (+10-20 %); short-K (768) and the TN weight-gradient
-    // shapes run faster register-staged at 3 workgroups / CU.  MD_GEMM_REGSTAGE / MD_GEMM_DMA force one variant (A/B).
-    static const bool force_regs = getenv("MD_GEMM_REGSTAGE") != nullptr;
-    static const bool force_dma = getenv("MD_GEMM_DMA") != nullptr;
-    const bool use_regs = force_regs || (!force_dma && ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024));
-#define LAUNCH(KERN)                                                                       \
-    do {                                                                                   \
-        if (a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<1, 1>), grid, block, 0, stream, *a);       \
-        else if (a->a_kcontig && !a->b_kcontig) hipLaunchKernelGGL((KERN<1, 0>), grid, block, 0, stream, *a); \
-        else if (!a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<0, 1>), grid, block, 0, stream, *a); \
-        else hipLaunchKernelGGL((KERN<0, 0>), grid, block, 0, stream, *a);                                     \
+#define LAUNCH(KERN, THREADS, ...)                                                                                          \
+    do {                                                                                                                   \
+        if (a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<1, 1 __VA_ARGS__>), grid, dim3(THREADS), 0, stream, *a);       \
+        else if (a->a_kcontig && !a->b_kcontig) hipLaunchKernelGGL((KERN<1, 0 __VA_ARGS__>), grid, dim3(THREADS), 0, stream, *a); \
+        else if (!a->a_kcontig && a->b_kcontig) hipLaunchKernelGGL((KERN<0, 1 __VA_ARGS__>), grid, dim3(THREADS), 0, stream, *a); \
+        else hipLaunchKernelGGL((KERN<0, 0 __VA_ARGS__>), grid, dim3(THREADS), 0, stream, *a);                                     \
     } while (0)
-    if (use_regs) LAUNCH(gemm_bf16_kernel); else LAUNCH(gemm_bf16_dma_kernel);
+#define COMMA ,
+    if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
+    else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
+    else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
+#undef COMMA
 #undef LAUNCH
     MD_LAUNCH_CHECK();
     return 0;

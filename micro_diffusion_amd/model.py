@@ -110,6 +110,8 @@ class LatentDiffusion(nn.Module):
         x = x.detach().float().contiguous()
         B = x.shape[0]
         T = (x.shape[-2] // dit.patch_size) * (x.shape[-1] // dit.patch_size)
+        if _noise is None and getattr(self, "_noise_fn", None) is not None:
+            _noise = self._noise_fn(B)            # test hook: recorded (rnd_normal, eps, mask_noise) per call
         if _noise is None:
             rnd = torch.randn([B, 1, 1, 1], device=x.device)
             eps = self.randn_like(x)

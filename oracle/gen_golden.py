@@ -15,14 +15,26 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+# The repo ships an import-alias package that is also called `micro_diffusion` (a regular package, which beats the
+# reference's namespace package on ANY path order), so the repo root must not be importable here: the oracle module is
+# loaded by file path instead.
+import importlib.util  # noqa: E402
+
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") not in (ROOT, HERE)]
 sys.path.insert(0, os.path.join(HERE, "stubs"))
 sys.path.insert(0, "/root/reference")
-sys.path.insert(0, ROOT)
 
 from micro_diffusion.models import dit as ref_dit            # noqa: E402  (the reference)
 from micro_diffusion.models import model as ref_model        # noqa: E402
 from micro_diffusion.models import utils as ref_utils        # noqa: E402
-from oracle import microdit_ref as orc                       # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("microdit_ref", os.path.join(HERE, "microdit_ref.py"))
+orc = importlib.util.module_from_spec(_spec)
+sys.modules["microdit_ref"] = orc
+_spec.loader.exec_module(orc)
+
+for _m in (ref_dit, ref_model, ref_utils):
+    assert _m.__file__.startswith("/root/reference/"), f"{_m.__name__} was not imported from the reference: {_m.__file__}"
 
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -147,7 +159,40 @@ def gen_init():
     print("init_seed18.npz")
 
 
+def gen_curve(steps=1000):
+    """1k optimisation steps of the REFERENCE model + torch AdamW + clip_grad_norm_(0.25) + linear warm-up
+    (configs/res_256_pretrain.yaml optimizer / scheduler / algorithms; Composer's step order)."""
+    cfg = orc.tiny_config()
+    torch.manual_seed(18)
+    dit = ref_dit_from_cfg(cfg)
+    model = ref_latent_diffusion(dit, -0.6, 1.2, 0.75)
+    model.train()
+    opt = torch.optim.AdamW(dit.parameters(), lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
+    losses, gnorms = [], []
+    for step in range(steps):
+        batch, rnd, epsn, mnoise = orc.curve_inputs(cfg, step)
+        rec = Recorded([rnd, epsn], [mnoise])
+        model.randn_like = lambda x: rec.randn()
+        for gr in opt.param_groups:
+            gr["lr"] = 2.4e-4 * orc.lr_factor("cosine_with_warmup", step, 2500, 250000, 0.33)
+        with mock.patch.object(torch, "randn", rec.randn), mock.patch.object(torch, "rand", rec.rand):
+            loss, _, _ = model(batch)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(dit.parameters(), 0.25)
+        opt.step()
+        losses.append(loss.item())
+        gnorms.append(gn.item())
+        if step % 100 == 0:
+            print(step, loss.item(), gn.item(), flush=True)
+    np.savez_compressed(os.path.join(OUT, "tiny_curve_1k.npz"), loss=np.array(losses), gnorm=np.array(gnorms))
+    print("tiny_curve_1k.npz")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "curve":
+        gen_curve()
+        sys.exit(0)
     gen_mask()
     gen_pos()
     gen_model("tiny_mask75", orc.tiny_config(), 4, 11, 0.75, -0.6, 1.2, 77)

@@ -487,3 +487,17 @@ def synth_batch(cfg: RefConfig, B: int, seed: int, cap_len: int = 77, mask_ratio
     epsn = torch.randn(B, cfg.in_channels, cfg.input_size, cfg.input_size, generator=g)
     mnoise = torch.rand(B, T, generator=g)
     return {"image_latents": lat, "caption_latents": cap, "drop_caption_mask": drop}, rnd, epsn, mnoise
+
+
+def curve_inputs(cfg: RefConfig, step: int, batch: int = 16, pool: int = 64, pool_seed: int = 77):
+    """Deterministic data + noise of step `step` of the 1k-step loss-curve parity run (tests/golden/tiny_curve_1k.npz):
+    a fixed pool of `pool` synthetic samples cycled in order, and per-step noise from its own CPU generator."""
+    pb, _, _, _ = synth_batch(cfg, pool, pool_seed)
+    idx = (torch.arange(batch) + step * batch) % pool
+    b = {k: v[idx].clone() for k, v in pb.items()}
+    g = torch.Generator().manual_seed(5000 + step)
+    T = (cfg.input_size // cfg.patch_size) ** 2
+    rnd = torch.randn(batch, 1, 1, 1, generator=g)
+    eps = torch.randn(batch, cfg.in_channels, cfg.input_size, cfg.input_size, generator=g)
+    mnoise = torch.rand(batch, T, generator=g)
+    return b, rnd, eps, mnoise
