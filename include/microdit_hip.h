@@ -93,12 +93,15 @@ typedef struct md_ln_args {
 typedef struct md_ln_bwd_args {
     const void* dz;  /* bf16 [rows, lddz]: grad of the (modulated) output */
     void* dx;        /* bf16 [rows, lddx] or NULL */
-    void* dscale;    /* f32 [samples, ldg] (+= via atomics) or NULL */
+    void* dscale;    /* f32 [samples, ldg], ZERO on entry: receives the per-sample sums dS = sum_t dz * xhat; if
+                        dscale_is_output it is turned into the modulation-scale gradient w * dS.  Required when dw is set
+                        (plain LayerNorms pass a zeroed scratch [samples, C]). */
     void* dshift;    /* f32 [samples, ldg] (+=) or NULL */
-    void* dw;        /* f32 [C] (+=) or NULL */
+    void* dw;        /* f32 [C] (+= sum_b (1 + scale_b) * dS_b) or NULL */
     int64_t lddz, lddx, ldg;
     int64_t rows_per_block; /* rows of one sample handled by one workgroup (column-sum granularity) */
     int32_t accumulate;     /* dx += instead of dx = */
+    int32_t dscale_is_output;
 } md_ln_bwd_args;
 
 int md_ln_fwd(const md_ln_args* a, hipStream_t stream);

@@ -269,7 +269,8 @@ extern "C" int md_act_bwd(const float* dy, const void* x, void* dx, int64_t n, i
 
 extern "C" int md_colsum(const void* x, int32_t x_is_f32, int64_t ld, float* out, int64_t rows, int64_t C, hipStream_t st) {
     if (!x || !out || rows <= 0 || C <= 0) return MD_BAD_ARG;
-    const int64_t rpb = 128;
+    int64_t rpb = 128;                       // rows per workgroup; short inputs (adaLN bias grads: 256 rows) get more,
+    while (rpb > 8 && ((C + 255) / 256) * ((rows + rpb - 1) / rpb) < 512) rpb /= 2;   // smaller chunks to fill the chip
     dim3 grid((unsigned)((C + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
     if (x_is_f32)
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, out, rows, C, rpb);

@@ -503,8 +503,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
     // Variant choice (measured on MI355X in the XL/2 shape mix, profiles/r1_gemm_variants.txt):
-    //  * 256 x 256 LDS-DMA tiles (8 waves) when they fill the chip (>= ~1 tile per CU) — longest prefetch distance,
-    //    half the global->LDS traffic per flop;
+    //  * 256 x 256 LDS-DMA tiles (8 waves, 1 workgroup / CU) only for K >= 2048 on grids that fill whole rounds of 256 CUs
+    //    (measured 950-995 TFLOP/s there, but 400-500 at K = 768..1024 where nothing hides a block's prologue/epilogue);
     //  * else 128 x 128: LDS-DMA for K >= 1024 with a K-contiguous operand, register-staged (3 workgroups / CU) for
     //    short K and the TN weight-gradient shapes.
     // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
@@ -514,7 +514,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
-    else if (tiles256 >= 224 && a->K >= 256) variant = 2;
+    else if (a->K >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
+        variant = 2;   // long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
     const int TMv = variant == 2 ? 256 : 128;
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);

@@ -2,7 +2,7 @@
 // wave shuffles (no LDS, no barriers in the forward), adaLN modulate fused into the same pass.
 //
 //  md_ln_fwd   y = LN(act(x + pos)) * w ; z = y * (1 + scale[b]) + shift[b]        (w, pos, act, modulate optional)
-//  md_ln_bwd   dx (+)= d/dx ; dscale[b] += w * sum_t dz * xhat ; dshift[b] += sum_t dz ; dw += (1 + scale[b]) * sum dz * xhat
+//  md_ln_bwd   dx (+)= d/dx ; dS[b] += sum_t dz * xhat ; dshift[b] += sum_t dz ; then (finish) dscale = w * dS, dw += sum_b (1 + scale[b]) * dS
 //  md_qkln_*   non-parametric LN over the whole q (or k) hidden width, in place (all heads concatenated)
 //
 // Reference: create_norm / nn.LayerNorm(bias=False) (utils.py:71-78) under Composer's low-precision LayerNorm
@@ -30,11 +30,12 @@ __device__ __forceinline__ float act_bwd(float v, int act) {
 }
 
 // Loads row `row` of the LN input into registers: v = act(x + pos).  raw keeps the pre-activation value.
-template <int NCH, bool KEEP_RAW>
+// GENERIC = false is the hot path (no pos table, no pre-norm activation): a pure 16-byte load + convert.
+template <int NCH, bool GENERIC, bool KEEP_RAW>
 __device__ __forceinline__ void load_row(const md_ln_args& p, int64_t row, int lane, float (&v)[NCH][8],
-                                         float (&raw)[NCH][8]) {
+                                         float (&raw)[KEEP_RAW ? NCH : 1][8]) {
     const bf16* xr = reinterpret_cast<const bf16*>(p.x) + row * p.ldx;
-    const float* pr = p.pos ? reinterpret_cast<const float*>(p.pos) + (row % p.pos_rows) * p.C : nullptr;
+    const float* pr = (GENERIC && p.pos) ? reinterpret_cast<const float*>(p.pos) + (row % p.pos_rows) * p.C : nullptr;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = lane * 8 + j * 512;
@@ -43,29 +44,55 @@ __device__ __forceinline__ void load_row(const md_ln_args& p, int64_t row, int l
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float f = bf2f(h[e]);
-                if (pr) f += pr[c + e];
-                if (KEEP_RAW) raw[j][e] = f;
-                v[j][e] = p.act ? act_fwd(f, p.act) : f;
+                if (GENERIC) {
+                    if (pr) f += pr[c + e];
+                    if (KEEP_RAW) raw[j][e] = f;
+                    if (p.act) f = act_fwd(f, p.act);
+                }
+                v[j][e] = f;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 v[j][e] = 0.f;
-                if (KEEP_RAW) raw[j][e] = 0.f;
+                if (GENERIC && KEEP_RAW) raw[j][e] = 0.f;
             }
         }
     }
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p) {
+__device__ __forceinline__ void load_cols_f32(const float* w, int C, int lane, float (&o)[NCH][8], float fill) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (w && c < C) {
+            const float4 a = *reinterpret_cast<const float4*>(w + c), b = *reinterpret_cast<const float4*>(w + c + 4);
+            o[j][0] = a.x; o[j][1] = a.y; o[j][2] = a.z; o[j][3] = a.w;
+            o[j][4] = b.x; o[j][5] = b.y; o[j][6] = b.z; o[j][7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[j][e] = fill;
+        }
+    }
+}
+
+// Each wave owns a run of consecutive rows (so the per-sample scale / shift vectors are re-read only when the
+// sample changes); the LN weight lives in registers for the whole run.
+template <int NCH, bool GENERIC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p, int64_t rows_per_wave) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t r0 = wave * rows_per_wave;
+    int64_t r1 = r0 + rows_per_wave;
+    if (r1 > p.rows) r1 = p.rows;
     const float invC = 1.f / (float)p.C;
-    for (int64_t row = wave; row < p.rows; row += nwaves) {
-        float v[NCH][8], raw[NCH][8];
-        load_row<NCH, false>(p, row, lane, v, raw);
+    float wk[NCH][8];
+    load_cols_f32<NCH>(reinterpret_cast<const float*>(p.w), (int)p.C, lane, wk, 1.f);
+    const bool mod = p.scale != nullptr;
+    for (int64_t row = r0; row < r1; ++row) {
+        float v[NCH][8], raw[1][8];
+        load_row<NCH, GENERIC, false>(p, row, lane, v, raw);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
@@ -89,25 +116,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p) {
             if (p.mean) reinterpret_cast<float*>(p.mean)[row] = mean;
             if (p.rstd) reinterpret_cast<float*>(p.rstd)[row] = rstd;
         }
-        const int64_t smp = p.rows_per_sample > 0 ? row / p.rows_per_sample : 0;
-        const float* w = reinterpret_cast<const float*>(p.w);
-        const bf16* sc = p.scale ? reinterpret_cast<const bf16*>(p.scale) + smp * p.ldmod : nullptr;
-        const bf16* sh = p.shift ? reinterpret_cast<const bf16*>(p.shift) + smp * p.ldmod : nullptr;
         bf16* orow = reinterpret_cast<bf16*>(p.out) + row * p.ldo;
+        const int64_t smp = mod ? row / p.rows_per_sample : 0;
+        const bf16* sc = mod ? reinterpret_cast<const bf16*>(p.scale) + smp * p.ldmod : nullptr;
+        const bf16* sh = (mod && p.shift) ? reinterpret_cast<const bf16*>(p.shift) + smp * p.ldmod : nullptr;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane * 8 + j * 512;
             if (c < p.C) {
-                bf16x8 o;
-                bf16x8 scv, shv;
-                if (sc) scv = ld_bf16x8(sc + c);
+                bf16x8 o, scv, shv;
+                if (mod) scv = ld_bf16x8(sc + c);     // L1/L2-resident per-sample vectors
                 if (sh) shv = ld_bf16x8(sh + c);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float y = (v[j][e] - mean) * rstd;
-                    if (w) y *= w[c + e];
-                    if (sc) y = bf2f(f2bf(y)) * (1.f + bf2f(scv[e]));
-                    if (sh) y += bf2f(shv[e]);
+                    float y = (v[j][e] - mean) * rstd * wk[j][e];
+                    if (mod) y = bf2f(f2bf(y)) * (1.f + bf2f(scv[e])) + (sh ? bf2f(shv[e]) : 0.f);
                     o[e] = f2bf(y);
                 }
                 st_bf16x8(orow + c, o);
@@ -116,24 +139,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p) {
     }
 }
 
-// grid = (row chunks per sample, samples); every block stays inside one sample so the per-sample column sums
-// (dscale / dshift) are reduced in registers + LDS and published with one atomicAdd per column per block.
-// ACT = false is the hot instantiation (no pre-norm activation): it keeps ~100 VGPRs -> 4-5 waves / SIMD.
-template <int NCH, bool ACT>
+// grid = (row chunks per sample, samples); every workgroup stays inside one sample: its per-column sums
+//   dS[b, c] += sum_t dz * xhat        dshift[b, c] += sum_t dz
+// are reduced in registers + LDS and published with one atomicAdd per column (few workgroups per sample -> little
+// contention).  dscale = w * dS and dw = sum_b (1 + scale_b) * dS are finished by ln_bwd_finish_kernel: summing dw with
+// atomics straight from here serialised ~2000 adds per address and tripled the kernel time.
+template <int NCH, bool GENERIC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_args b) {
     __shared__ float red[4][64 * 8 * NCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t rps = p.rows_per_sample > 0 ? p.rows_per_sample : p.rows;
     const int64_t smp = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * b.rows_per_block;
-    int64_t r1 = r0 + b.rows_per_block;
-    if (r1 > rps) r1 = rps;
+    const int64_t b0 = (int64_t)blockIdx.x * b.rows_per_block;
+    int64_t b1 = b0 + b.rows_per_block;
+    if (b1 > rps) b1 = rps;
+    const int64_t per_wave = (b1 - b0 + 3) / 4;
+    const int64_t r0 = b0 + wave * per_wave;
+    int64_t r1 = r0 + per_wave;
+    if (r1 > b1) r1 = b1;
     const float invC = 1.f / (float)p.C;
-    const float* w = reinterpret_cast<const float*>(p.w);
     const bf16* sc = p.scale ? reinterpret_cast<const bf16*>(p.scale) + smp * p.ldmod : nullptr;
-    const bool want_cols = b.dscale || b.dshift || b.dw;
+    const bool want_cols = b.dscale || b.dshift;
 
     float accS[NCH][8], accD[NCH][8], wm[NCH][8];   // wm = w * (1 + scale): d(out)/d(xhat) per column
+    load_cols_f32<NCH>(reinterpret_cast<const float*>(p.w), (int)p.C, lane, wm, 1.f);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = lane * 8 + j * 512;
@@ -143,21 +172,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
         for (int e = 0; e < 8; ++e) {
             accS[j][e] = 0.f;
             accD[j][e] = 0.f;
-            const float wv = (w && c < p.C) ? w[c + e] : 1.f;
-            const float mv = (sc && c < p.C) ? 1.f + bf2f(scv[e]) : 1.f;
-            wm[j][e] = wv * mv;
+            if (sc && c < p.C) wm[j][e] *= 1.f + bf2f(scv[e]);
         }
     }
-    for (int64_t lr = r0 + wave; lr < r1; lr += 4) {
+    for (int64_t lr = r0; lr < r1; ++lr) {
         const int64_t row = smp * rps + lr;
-        float v[NCH][8], raw[ACT ? NCH : 1][8];
-        if (ACT) {
-            float (&rw)[NCH][8] = reinterpret_cast<float (&)[NCH][8]>(raw);
-            load_row<NCH, true>(p, row, lane, v, rw);
-        } else {
-            float dummy[NCH][8];
-            load_row<NCH, false>(p, row, lane, v, dummy);
-        }
+        float v[NCH][8], raw[GENERIC ? NCH : 1][8];
+        load_row<NCH, GENERIC, GENERIC>(p, row, lane, v, raw);
         const float mean = reinterpret_cast<const float*>(p.mean)[row];
         const float rstd = reinterpret_cast<const float*>(p.rstd)[row];
         const bf16* dzr = reinterpret_cast<const bf16*>(b.dz) + row * b.lddz;
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float d = rstd * (g[j][e] - s1 - v[j][e] * s2);
-                        if (ACT) d *= act_bwd(raw[j][e], p.act);
+                        if (GENERIC && p.act) d *= act_bwd(raw[j][e], p.act);
                         if (b.accumulate) d += bf2f(prev[e]);
                         o[e] = f2bf(d);
                     }
@@ -209,33 +230,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
         }
     }
     if (!want_cols) return;
-    // ---- cross-wave reduction of the column sums, then one atomic per column
-    float* dscale = b.dscale ? reinterpret_cast<float*>(b.dscale) + smp * b.ldg : nullptr;
+    float* dS = b.dscale ? reinterpret_cast<float*>(b.dscale) + smp * b.ldg : nullptr;
     float* dshift = b.dshift ? reinterpret_cast<float*>(b.dshift) + smp * b.ldg : nullptr;
-    float* dw = reinterpret_cast<float*>(b.dw);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !dshift) break;
+        float* dst = pass == 0 ? dS : dshift;
+        if (!dst) continue;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[wave][lane * 8 + j * 512 + e] = pass == 0 ? accS[j][e] : accD[j][e];
         __syncthreads();
-        for (int c = threadIdx.x; c < p.C; c += 256) {
-            const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-            if (pass == 0) {
-                const float wc = w ? w[c] : 1.f;
-                if (dscale) unsafeAtomicAdd(dscale + c, wc * t);
-                if (dw) {
-                    const float m = sc ? 1.f + bf2f(sc[c]) : 1.f;
-                    unsafeAtomicAdd(dw + c, m * t);
-                }
-            } else {
-                unsafeAtomicAdd(dshift + c, t);
-            }
-        }
+        for (int c = threadIdx.x; c < p.C; c += 256) unsafeAtomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     }
+}
+
+// dw[c] += sum_b (1 + scale[b, c]) * dS[b, c];  optionally dS[b, c] *= w[c]  (dS becomes dscale).
+// grid = (column blocks of 256, sample chunks of 16): independent loads, one atomic per column per chunk.
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(float* dS, int64_t ldg, const float* w, const bf16* scale, int64_t ldmod,
+                                                            float* dw, int64_t B, int64_t C, int to_dscale) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t b0 = (int64_t)blockIdx.y * 16;
+    const float wc = w ? w[c] : 1.f;
+    float sv[16], mv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t b = b0 + i;
+        sv[i] = b < B ? dS[b * ldg + c] : 0.f;
+        mv[i] = (scale && b < B) ? 1.f + bf2f(scale[b * ldmod + c]) : 1.f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc += mv[i] * sv[i];
+        if (to_dscale && b0 + i < B) dS[(b0 + i) * ldg + c] = sv[i] * wc;
+    }
+    if (dw) unsafeAtomicAdd(dw + c, acc);
 }
 
 template <int NCH>
@@ -350,12 +382,20 @@ inline bool ln_args_ok(const md_ln_args* a) {
 
 extern "C" int md_ln_fwd(const md_ln_args* a, hipStream_t stream) {
     if (!ln_args_ok(a) || !a->out || a->ldo % 8) return MD_BAD_ARG;
-    if (a->C <= 512)
-        hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(ln_grid(a->rows)), dim3(256), 0, stream, *a);
-    else if (a->C <= 1024)
-        hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(ln_grid(a->rows)), dim3(256), 0, stream, *a);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(ln_grid(a->rows)), dim3(256), 0, stream, *a);
+    // consecutive rows per wave: enough waves to fill the chip (>= 8192), at most 8 rows each
+    int64_t rpw = (a->rows + 16383) / 16384;
+    if (rpw < 1) rpw = 1;
+    if (rpw > 8) rpw = 8;
+    const int64_t waves = (a->rows + rpw - 1) / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    const bool generic = a->act != MD_ACT_NONE || a->pos != nullptr;
+#define LNF(N, G) hipLaunchKernelGGL((ln_fwd_kernel<N, G>), grid, dim3(256), 0, stream, *a, rpw)
+    if (generic) {
+        if (a->C <= 512) LNF(1, true); else if (a->C <= 1024) LNF(2, true); else LNF(4, true);
+    } else {
+        if (a->C <= 512) LNF(1, false); else if (a->C <= 1024) LNF(2, false); else LNF(4, false);
+    }
+#undef LNF
     MD_LAUNCH_CHECK();
     return 0;
 }
@@ -364,16 +404,24 @@ extern "C" int md_ln_bwd(const md_ln_args* a, const md_ln_bwd_args* b, hipStream
     if (!ln_args_ok(a) || !b || !b->dz || !a->mean || !a->rstd || b->lddz % 8) return MD_BAD_ARG;
     if (b->dx && b->lddx % 8) return MD_BAD_ARG;
     if (b->rows_per_block <= 0) return MD_BAD_ARG;
+    if (b->dw && !b->dscale) return MD_BAD_ARG;   // dw is finished from the per-sample sums: a dS buffer is required
     const int64_t rps = a->rows_per_sample > 0 ? a->rows_per_sample : a->rows;
     if (a->rows % rps) return MD_BAD_ARG;
-    dim3 grid((unsigned)((rps + b->rows_per_block - 1) / b->rows_per_block), (unsigned)(a->rows / rps), 1);
-#define LNB(N, A) hipLaunchKernelGGL((ln_bwd_kernel<N, A>), grid, dim3(256), 0, stream, *a, *b)
-    if (a->act) {
+    const int64_t nsmp = a->rows / rps;
+    dim3 grid((unsigned)((rps + b->rows_per_block - 1) / b->rows_per_block), (unsigned)nsmp, 1);
+    const bool generic = a->act != MD_ACT_NONE || a->pos != nullptr;
+#define LNB(N, G) hipLaunchKernelGGL((ln_bwd_kernel<N, G>), grid, dim3(256), 0, stream, *a, *b)
+    if (generic) {
         if (a->C <= 512) LNB(1, true); else if (a->C <= 1024) LNB(2, true); else LNB(4, true);
     } else {
         if (a->C <= 512) LNB(1, false); else if (a->C <= 1024) LNB(2, false); else LNB(4, false);
     }
 #undef LNB
+    if (b->dscale && (b->dw || b->dscale_is_output))
+        hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((unsigned)((a->C + 255) / 256), (unsigned)((nsmp + 15) / 16)), dim3(256), 0, stream,
+                           reinterpret_cast<float*>(b->dscale), b->ldg, reinterpret_cast<const float*>(a->w),
+                           reinterpret_cast<const bf16*>(a->scale), a->ldmod, reinterpret_cast<float*>(b->dw), nsmp, a->C,
+                           b->dscale_is_output);
     MD_LAUNCH_CHECK();
     return 0;
 }

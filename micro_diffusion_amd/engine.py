@@ -144,11 +144,18 @@ class DiTEngine:
             rpb //= 2
         return int(max(1, min(rpb, rps)))
 
-    def ln_bwd(self, a, dz, dx, *, accumulate, wname=None, dscale=None, dshift=None, ldg=0, rps_total=None):
+    def ln_bwd(self, a, dz, dx, *, accumulate, wname=None, dscale=None, dshift=None, ldg=0):
+        """LayerNorm(+modulate) backward.  dscale / dshift: raw pointers into the (zeroed) fp32 adaLN gradient buffer for
+        modulated norms; plain norms get a zeroed [samples, C] scratch for the per-sample sums the weight grad is
+        finished from."""
         rps = a.rows_per_sample if a.rows_per_sample > 0 else a.rows
         rpb = self._rows_per_block(a.rows, rps)
+        is_out = 1 if dscale is not None else 0
+        if dscale is None and wname is not None:
+            scratch = self.zeros(a.rows // rps, a.C)
+            dscale, ldg = scratch.data_ptr(), a.C
         b = hip.LnBwdArgs(dz.data_ptr(), _p(dx), dscale, dshift, _p(self.G[wname + ".weight"]) if wname else None,
-                          a.C, a.C, ldg, rpb, 1 if accumulate else 0)
+                          a.C, a.C, ldg, rpb, 1 if accumulate else 0, is_out)
         hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd")
 
     def attn_args(self, q, k, v, o, lse, B, H, Sq, Skv, ldq, ldk, ldv, hid, *, do=None, dq=None, dk=None, dv=None,

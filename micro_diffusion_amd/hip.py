@@ -143,7 +143,7 @@ class LnArgs(Structure):
 class LnBwdArgs(Structure):
     _fields_ = [("dz", c_void_p), ("dx", c_void_p), ("dscale", c_void_p), ("dshift", c_void_p), ("dw", c_void_p),
                 ("lddz", c_int64), ("lddx", c_int64), ("ldg", c_int64), ("rows_per_block", c_int64),
-                ("accumulate", c_int32)]
+                ("accumulate", c_int32), ("dscale_is_output", c_int32)]
 
 
 class AttnArgs(Structure):

@@ -70,8 +70,10 @@ def test_ln_fwd_bwd(hip, C, rows, rps, mod, act, pos):
     dx0 = dx.clone()
     dmod = torch.zeros(B, 6 * C, device=DEV)
     dw = torch.zeros(C, device=DEV)
-    b = hip.LnBwdArgs(dz.data_ptr(), dx.data_ptr(), dmod[:, C:].data_ptr() if mod else None,
-                      dmod[:, 0:].data_ptr() if mod else None, dw.data_ptr(), C, C, 6 * C, 16, 1)
+    scratch = torch.zeros(B, C, device=DEV)      # plain LN: zeroed per-sample scratch for the weight-grad finish
+    b = hip.LnBwdArgs(dz.data_ptr(), dx.data_ptr(), dmod[:, C:].data_ptr() if mod else scratch.data_ptr(),
+                      dmod[:, 0:].data_ptr() if mod else None, dw.data_ptr(), C, C, 6 * C if mod else C, 16, 1,
+                      1 if mod else 0)
     hip.check(L.md_ln_bwd(byref(a), byref(b), st), "ln_bwd")
     torch.cuda.synchronize()
     close(dx.float() - dx0.float(), xr.grad, rel=3e-2, what="ln dx")
