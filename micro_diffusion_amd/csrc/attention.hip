@@ -44,18 +44,21 @@ __device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int pitch,
     return t.h;
 }
 
-// Stage 32 rows x HD of a [rows, ld] bf16 matrix (rows >= nrows are zero-filled) into an LDS tile.
+// Stage `nstage` rows x HD of a [rows, ld] bf16 matrix (rows >= nrows are zero-filled) into an LDS tile.
 template <int HD>
 __device__ __forceinline__ void stage_tile(unsigned char* tile, int pitch, const bf16* src, int64_t ld, int64_t row0,
-                                           int64_t nrows, int tid, int nthreads) {
+                                           int64_t nrows, int nstage, int tid, int nthreads) {
     constexpr int CPR = HD / 8;
-    for (int task = tid; task < 32 * CPR; task += nthreads) {
+    for (int task = tid; task < nstage * CPR; task += nthreads) {
         const int r = task / CPR, c = task % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * ld + c * 8);
         *reinterpret_cast<uint4*>(tile + r * pitch + c * 16) = v;
     }
 }
+
+constexpr int STG = 32;    // rows staged per barrier phase.  Measured (scripts/bench_attn.py): 32 beats 64 and 128 -- at S = 64..256 these
+                           // kernels stream q/k/v/o at 3.4-4.1 TB/s (HBM-bound); bigger phases only cost occupancy (LDS, VGPRs)
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
     bf16x8 o;
@@ -82,9 +85,7 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK];
-    unsigned char* sK = smem;
-    unsigned char* sV = smem + 32 * PK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
     const int hh = lane >> 5;
     const int64_t b = blockIdx.z, h = blockIdx.y;
@@ -110,11 +111,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
         for (int r = 0; r < 16; ++r) oacc[di][r] = 0.f;
     float m = -1e30f, l = 0.f;
 
-    for (int64_t key0 = 0; key0 < p.Skv; key0 += 32) {
+    for (int64_t kbase = 0; kbase < p.Skv; kbase += STG) {
         __syncthreads();
-        stage_tile<HD>(sK, PK, K, p.ldk, key0, p.Skv, tid, nthreads);
-        stage_tile<HD>(sV, PK, V, p.ldv, key0, p.Skv, tid, nthreads);
+        const int nst = (int)((p.Skv - kbase >= STG) ? STG : ((p.Skv - kbase + 31) / 32) * 32);
+        stage_tile<HD>(smem, PK, K, p.ldk, kbase, p.Skv, nst, tid, nthreads);
+        stage_tile<HD>(smem + STG * PK, PK, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
         __syncthreads();
+      for (int sub = 0; sub < STG / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+        const int64_t key0 = kbase + sub * 32;
+        const unsigned char* sK = smem + sub * 32 * PK;
+        const unsigned char* sV = smem + STG * PK + sub * 32 * PK;
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
                 oacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     tr_frag(sV, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, oacc[di], 0, 0, 0);
         }
+      }
     }
     if (qvalid) {
         bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
@@ -162,31 +169,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     }
 }
 
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-template <int HD>
-__global__ __launch_bounds__(256) void attn_delta_kernel(md_attn_args p) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = p.B * p.H * p.Sq;
-    if (idx >= total) return;
-    const int64_t q = idx % p.Sq, h = (idx / p.Sq) % p.H, b = idx / (p.Sq * p.H);
-    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + q * p.ldo + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + q * p.lddo + h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-        const bf16x8 a = ld_bf16x8(O + c * 8), d = ld_bf16x8(dO + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(d[e]);
-    }
-    reinterpret_cast<float*>(p.delta)[idx] = s;  // layout [B, H, Sq]: idx == (b*H + h)*Sq + q
-}
-
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK];
-    unsigned char* sK = smem;
-    unsigned char* sV = smem + 32 * PK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
     const int hh = lane >> 5;
     const int64_t b = blockIdx.z, h = blockIdx.y;
@@ -212,18 +198,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
         }
     }
     const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] : 0.f;
-    const float dlt = qvalid ? reinterpret_cast<const float*>(p.delta)[(b * p.H + h) * p.Sq + q] : 0.f;
+    // delta[q] = sum_d dO[q, d] * O[q, d]: this lane holds half of row q (its 8-wide d-chunks), the partner lane the rest
+    float dlt = 0.f;
+    if (qvalid) {
+        const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            const bf16x8 ov = ld_bf16x8(O + s * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt += bf2f(ov[e]) * bf2f(dof[s][e]);
+        }
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (qvalid && lane < 32) reinterpret_cast<float*>(p.delta)[(b * p.H + h) * p.Sq + q] = dlt;   // for the dK/dV kernel
     f32x16 dqacc[HD / 32];
 #pragma unroll
     for (int di = 0; di < HD / 32; ++di)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
 
-    for (int64_t key0 = 0; key0 < p.Skv; key0 += 32) {
+    for (int64_t kbase = 0; kbase < p.Skv; kbase += STG) {
         __syncthreads();
-        stage_tile<HD>(sK, PK, K, p.ldk, key0, p.Skv, tid, nthreads);
-        stage_tile<HD>(sV, PK, V, p.ldv, key0, p.Skv, tid, nthreads);
+        const int nst = (int)((p.Skv - kbase >= STG) ? STG : ((p.Skv - kbase + 31) / 32) * 32);
+        stage_tile<HD>(smem, PK, K, p.ldk, kbase, p.Skv, nst, tid, nthreads);
+        stage_tile<HD>(smem + STG * PK, PK, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
         __syncthreads();
+      for (int sub = 0; sub < STG / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+        const int64_t key0 = kbase + sub * 32;
+        const unsigned char* sK = smem + sub * 32 * PK;
+        const unsigned char* sV = smem + STG * PK + sub * 32 * PK;
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
                 dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     tr_frag(sK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
         }
+      }
     }
     if (qvalid) {
         bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
@@ -259,11 +263,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * PK + 2 * 32 * 4];
-    unsigned char* sQ = smem;
-    unsigned char* sdO = smem + 32 * PK;
-    float* sLse = reinterpret_cast<float*>(smem + 2 * 32 * PK);
-    float* sDlt = sLse + 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK + 2 * STG * 4];
+    float* sLseAll = reinterpret_cast<float*>(smem + 2 * STG * PK);
+    float* sDltAll = sLseAll + STG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
     const int hh = lane >> 5;
     const int64_t b = blockIdx.z, h = blockIdx.y;
@@ -299,16 +301,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
             dvacc[di][r] = 0.f;
         }
 
-    for (int64_t q0 = 0; q0 < p.Sq; q0 += 32) {
+    for (int64_t qbase = 0; qbase < p.Sq; qbase += STG) {
         __syncthreads();
-        stage_tile<HD>(sQ, PK, Q, p.ldq, q0, p.Sq, tid, nthreads);
-        stage_tile<HD>(sdO, PK, dO, p.lddo, q0, p.Sq, tid, nthreads);
-        if (tid < 32) {
-            const bool v = q0 + tid < p.Sq;
-            sLse[tid] = v ? LSE[q0 + tid] : 0.f;
-            sDlt[tid] = v ? DLT[q0 + tid] : 0.f;
+        const int nst = (int)((p.Sq - qbase >= STG) ? STG : ((p.Sq - qbase + 31) / 32) * 32);
+        stage_tile<HD>(smem, PK, Q, p.ldq, qbase, p.Sq, nst, tid, nthreads);
+        stage_tile<HD>(smem + STG * PK, PK, dO, p.lddo, qbase, p.Sq, nst, tid, nthreads);
+        for (int i = tid; i < nst; i += nthreads) {
+            const bool v = qbase + i < p.Sq;
+            sLseAll[i] = v ? LSE[qbase + i] : 0.f;
+            sDltAll[i] = v ? DLT[qbase + i] : 0.f;
         }
         __syncthreads();
+      for (int sub = 0; sub < STG / 32 && qbase + sub * 32 < p.Sq; ++sub) {
+        const int64_t q0 = qbase + sub * 32;
+        const unsigned char* sQ = smem + sub * 32 * PK;
+        const unsigned char* sdO = smem + STG * PK + sub * 32 * PK;
+        const float* sLse = sLseAll + sub * 32;
+        const float* sDlt = sDltAll + sub * 32;
         f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
                     tr_frag(sQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
             }
         }
+      }
     }
     if (kvalid) {
         bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
@@ -376,18 +386,15 @@ extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
 extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
-    const int64_t total = a->B * a->H * a->Sq;
     const int nwq = waves_for(a->Sq), nwk = waves_for(a->Skv);
     dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
     dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);
     if (a->hd == 64) {
-        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64 * nwq), 0, stream, *a);     // also writes delta
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * nwk), 0, stream, *a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64 * nwq), 0, stream, *a);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64 * nwk), 0, stream, *a);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64 * nwq), 0, stream, *a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64 * nwk), 0, stream, *a);
     }
     MD_LAUNCH_CHECK();
     return 0;

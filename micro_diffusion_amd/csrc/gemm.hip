@@ -147,7 +147,9 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 slab[row * SLAB_PITCH + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
-        __syncthreads();
+        // The slab is private to this wave: LDS operations of one wave execute in issue order, so no barrier is needed
+        // between its writes and its own read-back (a block-wide barrier here cost ~25 % of the K = 1024 kernels).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int lr = it * 8 + erow;
@@ -221,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 }
 
@@ -420,9 +422,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
         dma_tile<AKC, TM>(smem, A, p.lda, m0, p.M, kbeg, kend, wave, lane);
         dma_tile<BKC, TN>(smem + ATILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
     }
+    const int dbg = p.debug_flags;   // ablation (timing experiments only; results are wrong when set): 1 = no in-loop DMA,
+                                     // 2 = no fragment reads after the first tile, 4 = no barriers, 8 = no epilogue
+    bf16x8 fa[MI], fb[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[i][e] = f2bf(0.f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[j][e] = f2bf(0.f);
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
+        if (t + 1 < nt && !(dbg & 1)) {
             const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
             unsigned char* nb = smem + (cur ^ 1) * BUF;
             dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
@@ -431,16 +444,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                           // ... and every other wave's part of tile t
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();           // ... and every other wave's part of tile t
         const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
 #pragma unroll
         for (int ks = 0; ks < BKT / 16; ++ks) {
-            bf16x8 fa[MI], fb[2];
+            if (!(dbg & 2) || t == 0) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
+                for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -448,9 +462,174 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_barrier();                           // buffer `cur` is free for the DMA of tile t+2
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();           // buffer `cur` is free for the DMA of tile t+2
+    }
+    if (dbg & 8) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][1] + acc[MI - 1][1][15];   // keep acc live
+        return;
     }
     gemm_epilogue<MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * 64, batch, split, wave, lane);
+}
+
+// =====================================================================================================================
+// Ring variant: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave), k-slices of 32 streamed through a 4-stage
+// LDS ring (4 x 32 KiB) by LDS-DMA.  PMC counters on the 2-stage kernels showed the waves parked on vmcnt/barriers
+// (SQ_WAIT_ANY 37 %, MFMA busy 28 %): with one tile of prefetch the k-loop runs at memory latency (~3.2 K cycles per
+// tile vs ~1 K cycles of MFMA).  Here up to 3 stages (96 KiB) are in flight per CU, a 256^2 tile consumes half the
+// bytes per flop of a 128^2 one, ONE barrier per stage orders both the RAW (stage landed) and the WAR (buffer reuse)
+// hazards, and the per-lane DMA source pointers are computed once (per stage: one 64-bit add each).
+//   K-contiguous slice [256 rows][32 k]  (64-B rows, 16 rows per 1-KiB DMA): physical chunk = chunk ^ ((row >> 2) & 3)
+//   K-strided   slice  [32 k][256 cols]  (512-B rows, 2 rows per DMA)      : physical chunk = chunk ^ ((k & 3) << 2)
+// =====================================================================================================================
+constexpr int RK = 32;                       // k-slice depth
+constexpr int RNS = 4;                       // ring stages
+constexpr int RT = 256;                      // tile rows / columns
+constexpr int RSLICE = RT * RK * 2;          // 16 KiB per operand per stage
+constexpr int RSTAGE = 2 * RSLICE;           // 32 KiB per stage
+
+template <int KC>
+struct RingSrc {              // hoisted per-lane DMA sources of one operand: 2 DMAs per wave per stage
+    const bf16* ptr[2];       // source of k-slice 0 (or the zero word for out-of-range rows / columns)
+    int64_t step;             // element offset between consecutive k-slices
+    int kofs[2];              // k index (within a slice) this lane's 16-byte chunk starts at (K-contig) / its k-row (K-strided)
+    bool rowok[2];
+};
+
+template <int KC>
+__device__ __forceinline__ void ring_src_init(RingSrc<KC>& r, const bf16* base, int64_t ld, int64_t r0, int64_t rmax, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int chunk = wave * 2 + j;                       // 16 chunks of 1 KiB per slice
+        if (KC) {
+            const int row = chunk * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            r.rowok[j] = (r0 + row) < rmax;
+            r.kofs[j] = c * 8;
+            r.ptr[j] = base + (r0 + row) * ld + c * 8;
+        } else {
+            const int kk = chunk * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kk & 3) << 2);
+            r.rowok[j] = (r0 + c * 8) < rmax;
+            r.kofs[j] = kk;
+            r.ptr[j] = base + (int64_t)kk * ld + r0 + c * 8;
+        }
+    }
+    r.step = KC ? (int64_t)RK : (int64_t)RK * ld;
+}
+
+template <int KC>
+__device__ __forceinline__ void ring_dma(const RingSrc<KC>& r, unsigned char* slice, int64_t slice_idx, int64_t k0, int64_t kend, int wave) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool ok = r.rowok[j] && (k0 + r.kofs[j] < kend);
+        const bf16* src = ok ? r.ptr[j] + slice_idx * r.step : reinterpret_cast<const bf16*>(&g_zero16);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(slice + (wave * 2 + j) * 1024), 16, 0, 0);
+    }
+}
+
+template <int KC>
+__device__ __forceinline__ bf16x8 ring_frag(unsigned sbase, int row0, int ks, int lane) {
+    if (KC) {
+        const int row = row0 + (lane & 31);
+        const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
+        return asm_read_b128(sbase + row * 64 + c * 16);
+    } else {
+        const int li = lane & 15;
+        const int col = row0 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+        const int kk = ks * 16 + (lane >> 5) * 8 + (li >> 2);
+        const int pc = (col >> 3) ^ ((kk & 3) << 2);
+        bf16x4 lo, hi;
+        asm_read_tr2<4 * RT * 2>(sbase + kk * (RT * 2) + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(md_gemm_args p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RNS * RSTAGE];      // 128 KiB (epilogue slab: 8 x 8.5 KiB reuses it)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int ntn = (int)((p.N + RT - 1) / RT);
+    const int nwg = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t m0 = (int64_t)(logical / ntn) * RT;
+    const int64_t n0 = (int64_t)(logical % ntn) * RT;
+    const int batch = blockIdx.y / p.ksplit;
+    const int split = blockIdx.y % p.ksplit;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+    // split-K in whole 64-deep tiles (same partition as the other variants), walked in 32-deep slices
+    const int64_t ntk = (p.K + BKT - 1) / BKT;
+    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
+    const int64_t kbeg = (int64_t)split * tps * BKT;
+    int64_t kend = kbeg + tps * BKT;
+    if (kend > p.K) kend = p.K;
+    const int ns = kbeg < kend ? (int)((kend - kbeg + RK - 1) / RK) : 0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    RingSrc<AKC> sa;
+    RingSrc<BKC> sb;
+    ring_src_init<AKC>(sa, A + (AKC ? kbeg : kbeg * p.lda), p.lda, m0, p.M, wave, lane);
+    ring_src_init<BKC>(sb, B + (BKC ? kbeg : kbeg * p.ldb), p.ldb, n0, p.N, wave, lane);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+    // prologue: slices 0 .. RNS-2 in flight
+#pragma unroll
+    for (int s = 0; s < RNS - 1; ++s) {
+        if (s < ns) {
+            ring_dma<AKC>(sa, smem + s * RSTAGE, s, kbeg + (int64_t)s * RK, kend, wave);
+            ring_dma<BKC>(sb, smem + s * RSTAGE + RSLICE, s, kbeg + (int64_t)s * RK, kend, wave);
+        }
+    }
+    for (int t = 0; t < ns; ++t) {
+        // slices issued so far: min(ns, t + RNS - 1); slice t must have landed: allow (issued - t - 1) slices x 4 DMAs
+        const int inflight = ((t + RNS - 1 < ns) ? (t + RNS - 1) : ns) - t - 1;
+        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // slice t visible to all waves; every wave is done with slice t-1 (its buffer is free)
+        const int nxt = t + RNS - 1;
+        if (nxt < ns) {
+            unsigned char* nb = smem + (nxt % RNS) * RSTAGE;
+            ring_dma<AKC>(sa, nb, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
+            ring_dma<BKC>(sb, nb + RSLICE, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
+        }
+        const unsigned sA = lds0 + (t % RNS) * RSTAGE, sB = sA + RSLICE;
+#pragma unroll
+        for (int ks = 0; ks < RK / 16; ++ks) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = ring_frag<AKC>(sA, wm * 128 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = ring_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();          // all LDS reads done before the epilogue slab overwrites the ring
+    gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
 }
 
 // out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
@@ -487,7 +666,11 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
     return 0;
 }
 
-extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
+extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
+    md_gemm_args a_copy = *a_in;
+    static const char* dbg_env = getenv("MD_GEMM_DEBUG");
+    a_copy.debug_flags = dbg_env ? atoi(dbg_env) : 0;
+    const md_gemm_args* a = &a_copy;
     if (!a || !a->A || !a->B || !a->C) return MD_BAD_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->ksplit <= 0) return MD_BAD_ARG;
     // All global accesses are 16-byte chunks of 8 bf16 along the contiguous dimension: leading dimensions must be
@@ -509,15 +692,16 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
     //    short K and the TN weight-gradient shapes.
     // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
     static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring of 32-deep slices)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
+    else if (force && !strcmp(force, "ring256")) variant = 3;
     else if (a->K >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
         variant = 2;   // long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
-    const int TMv = variant == 2 ? 256 : 128;
+    const int TMv = variant >= 2 ? 256 : 128;
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
 #define LAUNCH(KERN, THREADS, ...)                                                                                          \
@@ -530,7 +714,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a, hipStream_t stream) {
 #define COMMA ,
     if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
     else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
-    else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
+    else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
+    else LAUNCH(gemm_bf16_ring_kernel, 512, );
 #undef COMMA
 #undef LAUNCH
     MD_LAUNCH_CHECK();

@@ -88,7 +88,7 @@ class GemmArgs(Structure):
         ("sAux", c_int64), ("sSplit", c_int64),
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
-        ("mode", c_int32), ("act", c_int32), ("alpha", c_float),
+        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("debug_flags", c_int32),
     ]
 
 
@@ -98,6 +98,10 @@ _lib = None
 def lib() -> ctypes.CDLL:
     """Load (once) the in-tree shared library; raise loudly when it is absent."""
     global _lib
+    if _lib is None and os.environ.get("MICRODIT_LIB"):       # experiments only: load an explicitly named build
+        _lib = ctypes.CDLL(os.environ["MICRODIT_LIB"])
+        _declare(_lib)
+        return _lib
     if _lib is None:
         stale = True
         if os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH):
