@@ -64,7 +64,8 @@ typedef struct md_gemm_args {
     int32_t mode; /* md_epilogue */
     int32_t act;  /* md_act */
     float alpha;
-    int32_t debug_flags; /* set by the library from MD_GEMM_DEBUG (timing ablations); callers pass 0 */
+    int32_t debug_flags;    /* set by the library from MD_GEMM_DEBUG (timing ablations); callers pass 0 */
+    int32_t raster_group_n; /* set by the library: column-tiles per L2 raster group */
 } md_gemm_args;
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);

@@ -43,6 +43,22 @@ __device__ __forceinline__ bf16x4 lds_tr_read(const unsigned char* p) {
     return t.h;
 }
 
+// Tile rasterisation.  Workgroup b runs on XCD b % 8 (private 4 MiB L2 each): first give every XCD a contiguous range of
+// logical tile ids, then walk the tiles in GROUPS of `group_n` column-tiles x all row-tiles (row-major inside a group), so
+// that the B (weight) sub-panel of a group stays L2-resident while the A row-panels stream through once per group.
+// (With plain N-fastest order and N = 3072, K = 1024 the 6 MiB weight panel cycled through L2 for every row of tiles.)
+__device__ __forceinline__ void tile_coords(int bid, int nwg, int ntn, int group_n, int& tm, int& tn) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int ntm = nwg / ntn;
+    const int per_group = group_n * ntm;
+    const int g = logical / per_group, rem = logical % per_group;
+    const int first_n = g * group_n;
+    const int gn = (ntn - first_n) < group_n ? (ntn - first_n) : group_n;
+    tm = rem / gn;
+    tn = first_n + rem % gn;
+}
+
 template <int KC>
 __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict__ base, int64_t ld, int64_t r0,
                                           int64_t rmax, int64_t k0, int64_t kend, int tid) {
@@ -239,14 +255,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
     // ---- XCD-aware tile order (block b runs on XCD b % 8; give each XCD a contiguous tile range) ----
     const int ntn = (int)((p.N + BN - 1) / BN);
     const int nwg = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int64_t m0 = (int64_t)(logical / ntn) * BM;
-    const int64_t n0 = (int64_t)(logical % ntn) * BN;
+    int tile_m, tile_n;
+    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int64_t n0 = (int64_t)tile_n * BN;
 
     const int batch = blockIdx.y / p.ksplit;
     const int split = blockIdx.y % p.ksplit;
@@ -323,7 +335,7 @@ typedef __attribute__((address_space(1))) void glb_void_t;
 // issues 4 of them per operand per tile for both supported geometries (128^2 x 4 waves, 256^2 x 8 waves).
 template <int KC, int ROWS>
 __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t rmax,
-                                         int64_t k0, int64_t kend, int wave, int lane) {
+                                         int64_t k0, int64_t kend, int wave, int lane, bool dbg_zero = false) {
     constexpr int RPC = 512 / ROWS;       // K-strided: k-rows per 1 KiB chunk (4 or 2)
     constexpr int LPR = 64 / RPC;         // lanes (16-byte chunks) per k-row (16 or 32)
 #pragma unroll
@@ -333,12 +345,12 @@ __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restric
             const int row = wave * 32 + j * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int64_t gr = r0 + row, gk = k0 + c * 8;
-            src = (gr < rmax && gk < kend) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
+            src = (gr < rmax && gk < kend && !dbg_zero) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
         } else {
             const int kk = (wave * 4 + j) * RPC + lane / LPR;
             const int c = (lane % LPR) ^ ((kk & 3) << 2);
             const int64_t gk = k0 + kk, gr = r0 + c * 8;
-            src = (gr < rmax && gk < kend) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
+            src = (gr < rmax && gk < kend && !dbg_zero) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
         }
         __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(s + (wave * 4 + j) * 1024), 16, 0, 0);
     }
@@ -390,14 +402,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
 
     const int ntn = (int)((p.N + TN - 1) / TN);
     const int nwg = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int64_t m0 = (int64_t)(logical / ntn) * TM;
-    const int64_t n0 = (int64_t)(logical % ntn) * TN;
+    int tile_m, tile_n;
+    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * TM;
+    const int64_t n0 = (int64_t)tile_n * TN;
     const int batch = blockIdx.y / p.ksplit;
     const int split = blockIdx.y % p.ksplit;
     const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
         dma_tile<BKC, TN>(smem + ATILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
     }
     const int dbg = p.debug_flags;   // ablation (timing experiments only; results are wrong when set): 1 = no in-loop DMA,
-                                     // 2 = no fragment reads after the first tile, 4 = no barriers, 8 = no epilogue
+                                     // 2 = no fragment reads after the first tile, 4 = no barriers, 8 = no epilogue, 32 = no vmcnt waits, 64 = DMA from the zero word
     bf16x8 fa[MI], fb[2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -438,11 +446,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
         if (t + 1 < nt && !(dbg & 1)) {
             const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
             unsigned char* nb = smem + (cur ^ 1) * BUF;
-            dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
-            dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
+            dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane, (dbg & 64) != 0);
+            dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane, (dbg & 64) != 0);
+            if (!(dbg & 32)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (!(dbg & 4)) __builtin_amdgcn_s_barrier();           // ... and every other wave's part of tile t
         const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
@@ -556,14 +564,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(md_gemm_args p) {
 
     const int ntn = (int)((p.N + RT - 1) / RT);
     const int nwg = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int64_t m0 = (int64_t)(logical / ntn) * RT;
-    const int64_t n0 = (int64_t)(logical % ntn) * RT;
+    int tile_m, tile_n;
+    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * RT;
+    const int64_t n0 = (int64_t)tile_n * RT;
     const int batch = blockIdx.y / p.ksplit;
     const int split = blockIdx.y % p.ksplit;
     const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
@@ -632,6 +636,133 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(md_gemm_args p) {
     gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
 }
 
+// =====================================================================================================================
+// Ping-pong variant: the ring kernel's geometry (256 x 256 tile, 8 waves, 4-slice LDS ring of 32-deep k-slices), but the
+// two 4-wave groups (waves 0-3 / 4-7: one wave of each group on every SIMD) run HALF A PERIOD APART.  In every phase one
+// group issues its 16 MFMAs for a slice (s_setprio 1) while the other group reads the 12 fragments of its next slice and
+// issues its share of the LDS-DMA for a slice 4 ahead, so the matrix pipe of every SIMD always has a wave feeding it
+// (the lock-step kernels above leave it idle during fragment-read latency, DMA issue and barrier skew: MFMA busy 28 %).
+// One s_barrier per phase orders all hazards:
+//   RAW  slice s is read by group 0 in global phase 2s-1 and by group 1 in phase 2s; every wave waits (counted vmcnt) for
+//        its own DMAs of slice s at the end of phase 2s-2, before the barrier that opens phase 2s-1;
+//   WAR  the buffer of slice s is re-filled (slice s + 4) by group 0 in phase 2s+1 and by group 1 in phase 2s+2, i.e. after
+//        the barrier that closes phase 2s, by which both groups have drained (lgkmcnt 0) their reads of slice s.
+// Group 1 is simply group 0's program shifted by one barrier.
+// =====================================================================================================================
+__device__ __forceinline__ void wait_vm_slices(int n) {      // at most n slices (4 DMAs each) of this wave outstanding
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RNS * RSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = wm;                                  // wave group = row half of the tile
+
+    const int ntn = (int)((p.N + RT - 1) / RT);
+    const int nwg = gridDim.x;
+    int tile_m, tile_n;
+    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * RT;
+    const int64_t n0 = (int64_t)tile_n * RT;
+    const int batch = blockIdx.y / p.ksplit;
+    const int split = blockIdx.y % p.ksplit;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+    const int64_t ntk = (p.K + BKT - 1) / BKT;
+    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
+    const int64_t kbeg = (int64_t)split * tps * BKT;
+    int64_t kend = kbeg + tps * BKT;
+    if (kend > p.K) kend = p.K;
+    const int ns = kbeg < kend ? (int)((kend - kbeg + RK - 1) / RK) : 0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[ks][i][e] = f2bf(0.f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fb[ks][j][e] = f2bf(0.f);
+    }
+
+    RingSrc<AKC> sa;
+    RingSrc<BKC> sb;
+    ring_src_init<AKC>(sa, A + (AKC ? kbeg : kbeg * p.lda), p.lda, m0, p.M, wave, lane);
+    ring_src_init<BKC>(sb, B + (BKC ? kbeg : kbeg * p.ldb), p.ldb, n0, p.N, wave, lane);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+    int issued = 0;                                     // slices whose DMA share this wave has issued
+#pragma unroll
+    for (int s = 0; s < RNS; ++s) {
+        if (s < ns) {
+            ring_dma<AKC>(sa, smem + s * RSTAGE, s, kbeg + (int64_t)s * RK, kend, wave);
+            ring_dma<BKC>(sb, smem + s * RSTAGE + RSLICE, s, kbeg + (int64_t)s * RK, kend, wave);
+            ++issued;
+        }
+    }
+    wait_vm_slices(issued - 1);                         // slice 0 landed (this wave's share)
+    __builtin_amdgcn_s_barrier();                       // opens global phase -1
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 idles through phase -1
+
+    for (int q = -1; q <= 2 * ns - 2; ++q) {            // local phase; global phase P = q + grp
+        if (q & 1) {                                    // ---- load role: fragments of slice s1, DMA share of slice sd
+            const int s1 = (q + 1) >> 1;
+            if (s1 < ns) {
+                const unsigned sA = lds0 + (s1 % RNS) * RSTAGE, sB = sA + RSLICE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[ks][i] = ring_frag<AKC>(sA, wm * 128 + i * 32, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[ks][j] = ring_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
+                }
+            }
+            const int sd = ((q - 1) >> 1) + RNS;
+            if (q >= 1 && sd < ns) {
+                unsigned char* nb = smem + (sd % RNS) * RSTAGE;
+                ring_dma<AKC>(sa, nb, sd, kbeg + (int64_t)sd * RK, kend, wave);
+                ring_dma<BKC>(sb, nb + RSLICE, sd, kbeg + (int64_t)sd * RK, kend, wave);
+                ++issued;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        } else {                                        // ---- compute role: slice q / 2 from the registers
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int P = q + grp;
+        if (!(P & 1)) wait_vm_slices(issued - ((P >> 1) + 2));   // slice P/2 + 1 is read in the next global phase
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // group 0 idles through the last phase
+    gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
+}
+
 // out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
                                                             int64_t sOut, int ksplit, int batch, int accumulate) {
@@ -692,16 +823,27 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     //    short K and the TN weight-gradient shapes.
     // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
     static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring of 32-deep slices)
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring), 4 = pp256 (ring + wave-group ping-pong)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
     else if (force && !strcmp(force, "ring256")) variant = 3;
+    else if (force && !strcmp(force, "pp256")) variant = 4;
     else if (a->K >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
         variant = 2;   // long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
     const int TMv = variant >= 2 ? 256 : 128;
+    {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
+        const int64_t ntn_ = (a->N + TMv - 1) / TMv;
+        const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;
+        int64_t g = (2 << 20) / (TMv * kspan * 2);
+        static const char* graster = getenv("MD_GEMM_GROUP_N");
+        if (graster) g = atoi(graster);
+        if (g < 1) g = 1;
+        if (g > ntn_) g = ntn_;
+        a_copy.raster_group_n = (int)g;
+    }
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
 #define LAUNCH(KERN, THREADS, ...)                                                                                          \
@@ -715,7 +857,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
     else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
     else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
-    else LAUNCH(gemm_bf16_ring_kernel, 512, );
+    else if (variant == 3) LAUNCH(gemm_bf16_ring_kernel, 512, );
+    else LAUNCH(gemm_bf16_pp_kernel, 512, );
 #undef COMMA
 #undef LAUNCH
     MD_LAUNCH_CHECK();

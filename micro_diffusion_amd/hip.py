@@ -88,7 +88,7 @@ class GemmArgs(Structure):
         ("sAux", c_int64), ("sSplit", c_int64),
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
-        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("debug_flags", c_int32),
+        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("debug_flags", c_int32), ("raster_group_n", c_int32),
     ]
 
 

@@ -88,3 +88,40 @@ def test_train_step_parity(hip, tag, cfgf, B, seed, ratio, pm, ps, cap):
     assert abs(gn_h - gn_o) <= 0.03 * gn_o
     bad = {k: v for k, v in per.items() if v > 0.15}
     assert not bad, bad
+
+
+def _res512_cfg():
+    """configs/res_512_*.yaml geometry on the Tiny widths: 64x64 latents (T = 1024 tokens), pos_interp_scale = 2."""
+    c = orc.tiny_config(input_size=64)
+    c.pos_interp_scale = 2.0
+    return c
+
+
+@pytest.mark.parametrize("ratio", [0.75, 0.0])
+def test_res512_stage_parity(hip, ratio):
+    """Stage 3 / 4 shapes (BASELINE.json configs[3..4]): T = 1024 mixer tokens, 256 (mask 0.75) or 1024 (mask 0) backbone
+    tokens, P_mean 0 / P_std 0.6 — same tolerances as the 256-res cases."""
+    cfg = _res512_cfg()
+    seed, B, pm, ps = 31, 2, 0.0, 0.6
+    sd = orc.synth_state_dict(cfg, seed)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1)
+    osd = {k: v.clone().requires_grad_(k not in ("pos_embed", "mask_token")) for k, v in sd.items()}
+    oloss = orc.latent_diffusion_forward(osd, cfg, batch, rnd, epsn, mnoise, ratio, pm, ps)
+    oloss.backward()
+    model = build_product(cfg, sd, pm, ps, ratio)
+    cond = (batch["caption_latents"] * batch["drop_caption_mask"].view(-1, 1, 1, 1).half()).cuda()
+    loss = model.edm_loss(batch["image_latents"].cuda(), cond, mask_ratio=ratio,
+                          _noise=(rnd.cuda(), epsn.cuda(), mnoise.cuda() if ratio > 0 else None))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - oloss.item()) <= 0.01 * abs(oloss.item()), (loss.item(), oloss.item())
+    grads = {k: p.grad.detach().cpu() for k, p in model.dit.named_parameters()}
+    gn_h = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    gn_o = float(torch.sqrt(sum((osd[k].grad.double() ** 2).sum() for k in grads)))
+    dot = float(sum((grads[k].double() * osd[k].grad.double()).sum() for k in grads))
+    assert dot / (gn_h * gn_o) >= 0.99 and abs(gn_h - gn_o) <= 0.03 * gn_o, (dot / (gn_h * gn_o), gn_h, gn_o)
+    if ratio > 0:       # mask of the 1024-token row: bit-exact
+        with torch.no_grad():
+            out = model.dit(batch["image_latents"].float().cuda(), torch.zeros(B).cuda(), cond, mask_ratio=ratio,
+                            mask_noise=mnoise.cuda())
+        assert torch.equal(out["mask"].cpu(), orc.get_mask(mnoise, ratio)["mask"])
