@@ -501,3 +501,40 @@ def curve_inputs(cfg: RefConfig, step: int, batch: int = 16, pool: int = 64, poo
     eps = torch.randn(batch, cfg.in_channels, cfg.input_size, cfg.input_size, generator=g)
     mnoise = torch.rand(batch, T, generator=g)
     return b, rnd, eps, mnoise
+
+
+def edm_sampler(sd: SD, cfg: RefConfig, latents: Tensor, y: Tensor, steps: int, guidance: float = 1.0, sigma_min=0.002,
+                sigma_max=80.0, rho=7.0, sigma_data: float = 0.9) -> Tensor:
+    """Deterministic EDM Heun sampler with classifier-free guidance (model.py:231-297, dit.py:521-550; S_churn = 0 so
+    no noise is injected): fp64 state, network evaluated in fp32 at mask ratio 0."""
+    def denoise(x64, sigma):
+        x = x64.to(torch.float32)
+        s = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1, 1, 1, 1)
+        c_skip = sigma_data ** 2 / (s ** 2 + sigma_data ** 2)
+        c_out = s * sigma_data / (s ** 2 + sigma_data ** 2).sqrt()
+        c_in = 1 / (sigma_data ** 2 + s ** 2).sqrt()
+        t = (s.log() / 4).flatten()
+        if guidance > 1.0:
+            xin = torch.cat([c_in * x, c_in * x], 0)
+            yy = torch.cat([y, torch.zeros_like(y)], 0)
+            Fx, _ = dit_forward(sd, cfg, xin, t, yy, 0.0)
+            cond, uncond = Fx.chunk(2, 0)
+            Fx = uncond + guidance * (cond - uncond)
+        else:
+            Fx, _ = dit_forward(sd, cfg, c_in * x, t, y, 0.0)
+        return (c_skip * x + c_out * Fx).to(torch.float64)
+
+    idx = torch.arange(steps, dtype=torch.float64)
+    t_steps = (sigma_max ** (1 / rho) + idx / (steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    t_steps = torch.cat([t_steps, torch.zeros(1, dtype=torch.float64)])
+    x_next = latents.to(torch.float64) * t_steps[0]
+    with torch.no_grad():
+        for i in range(steps):
+            t_cur, t_next = t_steps[i], t_steps[i + 1]
+            x_hat = x_next
+            d_cur = (x_hat - denoise(x_hat, t_cur)) / t_cur
+            x_next = x_hat + (t_next - t_cur) * d_cur
+            if i < steps - 1:
+                d_prime = (x_next - denoise(x_next, t_next)) / t_next
+                x_next = x_hat + (t_next - t_cur) * (0.5 * d_cur + 0.5 * d_prime)
+    return x_next.to(torch.float32)
