@@ -335,11 +335,13 @@ typedef __attribute__((address_space(1))) void glb_void_t;
 // issues 4 of them per operand per tile for both supported geometries (128^2 x 4 waves, 256^2 x 8 waves).
 template <int KC, int ROWS>
 __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t rmax,
-                                         int64_t k0, int64_t kend, int wave, int lane, bool dbg_zero = false) {
+                                         int64_t k0, int64_t kend, int wave, int lane, bool dbg_zero = false, int j0 = 0,
+                                         int j1 = 4) {
     constexpr int RPC = 512 / ROWS;       // K-strided: k-rows per 1 KiB chunk (4 or 2)
     constexpr int LPR = 64 / RPC;         // lanes (16-byte chunks) per k-row (16 or 32)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if (j < j0 || j >= j1) continue;
         const bf16* src;
         if (KC) {
             const int row = wave * 32 + j * 8 + (lane >> 3);
@@ -389,7 +391,7 @@ __device__ __forceinline__ bf16x8 dma_frag(unsigned sbase, int row0, int ks, int
 }
 
 // WM x WN waves; every wave owns (MI * 32) x 64 outputs.  TM = WM * MI * 32, TN = WN * 64.
-template <int AKC, int BKC, int WM, int WN, int MI>
+template <int AKC, int BKC, int WM, int WN, int MI, bool PACED = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_args p) {
     constexpr int TM = WM * MI * 32, TN = WN * 64;
     constexpr int ATILE = TM * 128, BTILE = TN * 128;          // bytes (64 k x 2 B per row / column)
@@ -441,6 +443,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) fb[j][e] = f2bf(0.f);
+    if (PACED) {
+        // One barrier per tile: the DMAs of tile t+1 are issued AFTER the barrier that opens tile t (all waves are done with
+        // tile t-1, whose buffer they overwrite) and paced one chunk of each operand per k-step, instead of an 8-deep burst at
+        // the top of the loop that backs up the vector-memory queue in front of the wave's MFMAs.
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t has landed
+            __builtin_amdgcn_s_barrier();
+            const bool more = t + 1 < nt;
+            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
+            unsigned char* nb = smem + (cur ^ 1) * BUF;
+            const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
+#pragma unroll
+            for (int ks = 0; ks < BKT / 16; ++ks) {
+                if (more) {
+                    dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane, false, ks, ks + 1);
+                    dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane, false, ks, ks + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    } else
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt && !(dbg & 1)) {
@@ -823,17 +858,20 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     //    short K and the TN weight-gradient shapes.
     // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
     static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring), 4 = pp256 (ring + wave-group ping-pong)
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring), 4 = pp256 (ring + wave-group ping-pong),
+                   // 5 / 6 = paced128 / paced256 (2-stage, DMA issue paced over the k-steps, one barrier per tile)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
     else if (force && !strcmp(force, "ring256")) variant = 3;
     else if (force && !strcmp(force, "pp256")) variant = 4;
+    else if (force && !strcmp(force, "paced128")) variant = 5;
+    else if (force && !strcmp(force, "paced256")) variant = 6;
     else if (a->K >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
-        variant = 2;   // long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
+        variant = 6;   // paced256: long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
-    const int TMv = variant >= 2 ? 256 : 128;
+    const int TMv = (variant >= 2 && variant != 5) ? 256 : 128;
     {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
         const int64_t ntn_ = (a->N + TMv - 1) / TMv;
         const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;
@@ -858,7 +896,9 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
     else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
     else if (variant == 3) LAUNCH(gemm_bf16_ring_kernel, 512, );
-    else LAUNCH(gemm_bf16_pp_kernel, 512, );
+    else if (variant == 4) LAUNCH(gemm_bf16_pp_kernel, 512, );
+    else if (variant == 5) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2 COMMA true);
+    else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4 COMMA true);
 #undef COMMA
 #undef LAUNCH
     MD_LAUNCH_CHECK();

@@ -93,6 +93,15 @@ class DiTEngine:
                    res=_p(res), M=M, N=K, K=N, lda=lddy or N, ldb=K, ldc=K, ldaux=K, ldr=K, batch=1, ksplit=1,
                    a_kcontig=1, b_kcontig=0, mode=mode, act=act, alpha=1.0)
 
+    def _fused12(self, pre):
+        """True when w1.weight and w2.weight of a SwiGLU FFN are adjacent in the flat buffers (no biases in between), so
+        [w1; w2] is one [2f, d] matrix: forward, dgrad and wgrad then run as ONE GEMM each."""
+        w1, w2 = self.S.get(pre + ".w1.weight"), self.S.get(pre + ".w2.weight")
+        if w1 is None or w2 is None or (pre + ".w1.bias") in self.P:
+            return False
+        return (w2.data_ptr() == w1.data_ptr() + w1.numel() * 2 and
+                self.G[pre + ".w2.weight"].data_ptr() == self.G[pre + ".w1.weight"].data_ptr() + w1.numel() * 4)
+
     def _ksplit(self, out_rows, out_cols, contraction, batch=1):
         """Split-K factor for GEMMs whose output is too small to fill the chip (weight gradients, skinny dgrads):
         aim at ~3 workgroups per CU, keep >= 512 contraction elements per split, stay inside the workspace."""
@@ -253,8 +262,11 @@ class DiTEngine:
         gate_mlp = mp + 2 * 5 * d
         if not bp.moe:
             t.h12 = self.empty(M, 2 * f)
-            self.lin_fwd(t.xm3, n + ".mlp.w1", t.h12, M, f, d, ldc=2 * f)
-            self.lin_fwd(t.xm3, n + ".mlp.w2", t.h12, M, f, d, ldc=2 * f, ooff=f)
+            if self._fused12(n + ".mlp"):
+                self.lin_fwd(t.xm3, n + ".mlp.w1", t.h12, M, 2 * f, d)          # [w1; w2] as one [2f, d] weight
+            else:
+                self.lin_fwd(t.xm3, n + ".mlp.w1", t.h12, M, f, d, ldc=2 * f)
+                self.lin_fwd(t.xm3, n + ".mlp.w2", t.h12, M, f, d, ldc=2 * f, ooff=f)
             t.a = self.empty(M, f)
             hip.check(L.md_swiglu_fwd(t.h12.data_ptr(), 2 * f, t.a.data_ptr(), f, M, f, st), "swiglu")
             self.lin_fwd(t.a, n + ".mlp.w3", x3, M, d, f, mode=hip.EPI_RESIDUAL, res=x2, gate=gate_mlp, ldg=6 * d, rps=S,
@@ -310,10 +322,14 @@ class DiTEngine:
             self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
             dh12 = self.empty(M, 2 * f)
             hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd")
-            self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, f, d, lddy=2 * f)
-            self.lin_wgrad(dh12, t.xm3, n + ".mlp.w2", M, f, d, lddy=2 * f, dyoff=f)
-            self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, f, d, lddy=2 * f)
-            self.lin_dgrad(dh12, n + ".mlp.w2", dxm3, M, f, d, lddy=2 * f, dyoff=f, mode=hip.EPI_RESIDUAL, res=dxm3)
+            if self._fused12(n + ".mlp"):
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, 2 * f, d)
+                self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, 2 * f, d)
+            else:
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, f, d, lddy=2 * f)
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w2", M, f, d, lddy=2 * f, dyoff=f)
+                self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, f, d, lddy=2 * f)
+                self.lin_dgrad(dh12, n + ".mlp.w2", dxm3, M, f, d, lddy=2 * f, dyoff=f, mode=hip.EPI_RESIDUAL, res=dxm3)
         else:
             E, k, ldl = cfg.num_experts, t.k, t.ldl
             Bk = B * k
@@ -477,8 +493,11 @@ class DiTEngine:
         self.ln_fwd(self.ln_args(y1, "y_emb_preprocess.norm2", cb.xn2, Mc, D, mean=cb.st2[0], rstd=cb.st2[1], rps=Lc))
         fc = caption_ffn_hidden(cfg)
         cb.h12 = self.empty(Mc, 2 * fc)
-        self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w1", cb.h12, Mc, fc, D, ldc=2 * fc)
-        self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w2", cb.h12, Mc, fc, D, ldc=2 * fc, ooff=fc)
+        if self._fused12("y_emb_preprocess.mlp"):
+            self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w1", cb.h12, Mc, 2 * fc, D)
+        else:
+            self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w1", cb.h12, Mc, fc, D, ldc=2 * fc)
+            self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w2", cb.h12, Mc, fc, D, ldc=2 * fc, ooff=fc)
         cb.a = self.empty(Mc, fc)
         hip.check(L.md_swiglu_fwd(cb.h12.data_ptr(), 2 * fc, cb.a.data_ptr(), fc, Mc, fc, st), "swiglu")
         y2 = self.empty(Mc, D)
@@ -665,11 +684,15 @@ class DiTEngine:
         self.lin_dgrad(dy, "y_emb_preprocess.mlp.w3", da, Mc, D, fc)
         dh12 = self.empty(Mc, 2 * fc)
         hip.check(L.md_swiglu_bwd(da.data_ptr(), fc, cb.h12.data_ptr(), 2 * fc, dh12.data_ptr(), 2 * fc, Mc, fc, st), "swiglu_bwd")
-        self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w1", Mc, fc, D, lddy=2 * fc)
-        self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w2", Mc, fc, D, lddy=2 * fc, dyoff=fc)
         dxn2 = self.empty(Mc, D)
-        self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w1", dxn2, Mc, fc, D, lddy=2 * fc)
-        self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w2", dxn2, Mc, fc, D, lddy=2 * fc, dyoff=fc, mode=hip.EPI_RESIDUAL, res=dxn2)
+        if self._fused12("y_emb_preprocess.mlp"):
+            self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w1", Mc, 2 * fc, D)
+            self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w1", dxn2, Mc, 2 * fc, D)
+        else:
+            self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w1", Mc, fc, D, lddy=2 * fc)
+            self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w2", Mc, fc, D, lddy=2 * fc, dyoff=fc)
+            self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w1", dxn2, Mc, fc, D, lddy=2 * fc)
+            self.lin_dgrad(dh12, "y_emb_preprocess.mlp.w2", dxn2, Mc, fc, D, lddy=2 * fc, dyoff=fc, mode=hip.EPI_RESIDUAL, res=dxn2)
         a = self.ln_args(cb.y1, "y_emb_preprocess.norm2", None, Mc, D, mean=cb.st2[0], rstd=cb.st2[1], rps=Lc)
         self.ln_bwd(a, dxn2, dy, accumulate=True, wname="y_emb_preprocess.norm2")
         heads_c = D // cfg.head_dim
