@@ -861,6 +861,7 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring), 4 = pp256 (ring + wave-group ping-pong),
                    // 5 / 6 = paced128 / paced256 (2-stage, DMA issue paced over the k-steps, one barrier per tile)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
+    const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
@@ -868,13 +869,15 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     else if (force && !strcmp(force, "pp256")) variant = 4;
     else if (force && !strcmp(force, "paced128")) variant = 5;
     else if (force && !strcmp(force, "paced256")) variant = 6;
-    else if (a->K >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
+    else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
+        variant = 6;   // weight gradients (TN): 830-1020 TFLOP/s when the caller's split-K makes ~one full round of 256 workgroups
+                       // (profiles/r1_wgrad_splitk.txt), and ahead of the 128^2 kernels (600-740) at every split factor measured
+    else if (kspan >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
         variant = 6;   // paced256: long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
     const int TMv = (variant >= 2 && variant != 5) ? 256 : 128;
     {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
         const int64_t ntn_ = (a->N + TMv - 1) / TMv;
-        const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;
         int64_t g = (2 << 20) / (TMv * kspan * 2);
         static const char* graster = getenv("MD_GEMM_GROUP_N");
         if (graster) g = atoi(graster);

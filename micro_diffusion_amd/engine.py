@@ -51,7 +51,7 @@ class DiTEngine:
         self.L = hip.lib()
         self.wgrad_target_blocks = 768
         self.gemm_profile = None
-        self.ws = torch.empty(64 << 20, device=self.dev, dtype=F32)   # 256 MiB split-K workspace
+        self.ws = torch.empty(128 << 20, device=self.dev, dtype=F32)  # 512 MiB split-K workspace
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
@@ -103,13 +103,27 @@ class DiTEngine:
                 self.G[pre + ".w2.weight"].data_ptr() == self.G[pre + ".w1.weight"].data_ptr() + w1.numel() * 4)
 
     def _ksplit(self, out_rows, out_cols, contraction, batch=1):
-        """Split-K factor for GEMMs whose output is too small to fill the chip (weight gradients, skinny dgrads):
-        aim at ~3 workgroups per CU, keep >= 512 contraction elements per split, stay inside the workspace."""
+        """Split-K factor for GEMMs whose output is too small to fill the chip (weight gradients, skinny dgrads).
+
+        Long contractions run on the 256 x 256 single-workgroup-per-CU kernel, which is at its best (830-1020 TFLOP/s,
+        profiles/r1_wgrad_splitk.txt) when tiles x splits make whole rounds of 256 workgroups: pick the factor that
+        minimises  rounds x (K / ks + ~1024 k of un-overlapped prologue + fp32 epilogue)  + the slice reduction's
+        traffic.  Short contractions keep the 128 x 128 rule (~3 workgroups per CU, >= 512 k per split)."""
+        ws_cap = max(1, self.ws.numel() // (out_rows * out_cols * batch))
+        t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256) * batch
+        out_mb = out_rows * out_cols * batch * 4 / 4e6              # microseconds to move the output once at ~4 TB/s
+        best, best_cost = 1, None
+        for ks in range(1, min(64, ws_cap, max(1, contraction // 2048)) + 1):
+            rounds = -(-t256 * ks // 256)
+            cost = rounds * (contraction / ks + 1024) * 0.0335 + (2 if ks == 1 else ks + 2) * out_mb
+            if best_cost is None or cost < best_cost:
+                best, best_cost = ks, cost
+        if contraction // best >= 2048 and t256 * best >= 128:
+            return best
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * batch
         ks = max(1, self.wgrad_target_blocks // tiles)
         ks = min(ks, max(1, contraction // 512))
-        ks = min(ks, max(1, self.ws.numel() // (out_rows * out_cols * batch)))
-        return max(1, ks)
+        return max(1, min(ks, ws_cap))
 
     def gemm_f32_acc(self, *, out_ptr, M, N, K, ldo, batch=1, sOut=0, accumulate=True, **operands):
         """fp32 C (+)= A B^T with automatic split-K: partial products go to a workspace as dense fp32 slices and are
