@@ -64,7 +64,7 @@ typedef struct md_gemm_args {
     int32_t mode; /* md_epilogue */
     int32_t act;  /* md_act */
     float alpha;
-    int32_t debug_flags;    /* set by the library from MD_GEMM_DEBUG (timing ablations); callers pass 0 */
+    int32_t reserved0;      /* pass 0 */
     int32_t raster_group_n; /* set by the library: column-tiles per L2 raster group */
 } md_gemm_args;
 
@@ -207,6 +207,10 @@ int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------- probes (tests only) */
 int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);
 int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream);
+/* Profiling aid: when buf != NULL every GEMM workgroup writes 8 int64 {t_entry, t_prologue_done, t_loop_done,
+ * t_stores_drained (shader clock), wall clock (100 MHz), XCC_ID << 32 | HW_ID, 0, 0} at buf[linear_workgroup_id * 8];
+ * NULL switches it off.  Not for production runs. */
+int md_debug_gemm_timeline(void* buf);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,29 @@ __device__ __forceinline__ void tile_coords(int bid, int nwg, int ntn, int group
     tn = first_n + rem % gn;
 }
 
+// Optional per-workgroup timeline (md_debug_gemm_timeline): shader-clock stamps at entry, after the prologue (first tile
+// landed), after the k-loop and after the epilogue's stores have drained, plus HW_ID (XCD / CU / SIMD placement).  Off
+// (null pointer) in normal operation; used by scripts/gemm_timeline.py to attribute a launch's time to its phases.
+__device__ long long* g_timeline = nullptr;
+
+__device__ __forceinline__ void timeline_stamp(long long* tl, int slot) {
+    if (tl && threadIdx.x == 0) tl[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = clock64();
+}
+__device__ __forceinline__ void timeline_finish(long long* tl) {
+    if (!tl) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include the store drain in the epilogue stamp
+    if (threadIdx.x == 0) {
+        long long* r = tl + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        r[3] = clock64();
+        r[4] = wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        r[5] = ((long long)xcc << 32) | hw;
+    }
+}
+
 template <int KC>
 __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict__ base, int64_t ld, int64_t r0,
                                           int64_t rmax, int64_t k0, int64_t kend, int tid) {
@@ -147,14 +170,51 @@ __device__ __forceinline__ float apply_dact(float v, int act) {
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&acc)[MI][2], unsigned char* smem, int64_t mw0,
                                               int64_t nw0, int batch, int split, int wave, int lane) {
-    __syncthreads();
     float* slab = reinterpret_cast<float*>(smem) + wave * SLAB_FLOATS;
     const int mode = p.mode;
     const float alpha = p.alpha;
     const int erow = lane >> 3;        // 0..7
     const int ecol = (lane & 7) * 8;   // 0..56
+    const int64_t gc = nw0 + ecol;
+    const bool col_ok = gc < p.N;
+
+    // Every global operand of the fused ops (residual, gate, activation input, bias) is requested up front, before the
+    // barrier and the LDS transpose, so their HBM round trips overlap each other and the slab traffic.  Issued one by one
+    // at their point of use they serialised 8-16 dependent ~1 us loads per workgroup: the gated-residual epilogue took
+    // 18.9 k cycles against 7.5 k for the plain store (profiles/r1_gemm_timeline.txt).
+    bf16x8 pre[2][4], gpre[2][4];      // double-buffered over mi: the set of mi + 1 is requested before mi is processed
+    float bv[8];
+    const bool has_pre = mode == MD_EPI_RESIDUAL || mode == MD_EPI_DACT;
+    const bool has_gate = mode == MD_EPI_RESIDUAL && p.gate != nullptr;
+    const bf16* pb = mode == MD_EPI_RESIDUAL ? reinterpret_cast<const bf16*>(p.res)
+                                             : reinterpret_cast<const bf16*>(p.aux) + (int64_t)batch * p.sAux;
+    const int64_t ldp = mode == MD_EPI_RESIDUAL ? p.ldr : p.ldaux;
+    const unsigned rps = has_gate ? (unsigned)p.rows_per_sample : 1u;
+    auto prefetch = [&](int mi) {
+        if (!has_pre) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int64_t gr = mw0 + mi * 32 + it * 8 + erow;
+            if (gr < p.M && col_ok) {
+                pre[mi & 1][it] = ld_bf16x8(pb + gr * ldp + gc);
+                if (has_gate)
+                    gpre[mi & 1][it] = ld_bf16x8(reinterpret_cast<const bf16*>(p.gate) + (int64_t)((unsigned)gr / rps) * p.ldg + gc);
+            }
+        }
+    };
+    prefetch(0);
+    if (p.bias && col_ok) {
+        const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)batch * p.sBias + gc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = bp[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+    __syncthreads();   // every wave is done reading the staging buffers the slabs alias
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        if (mi + 1 < MI) prefetch(mi + 1);
         // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -170,8 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
         for (int it = 0; it < 4; ++it) {
             const int lr = it * 8 + erow;
             const int64_t gr = mw0 + mi * 32 + lr;
-            const int64_t gc = nw0 + ecol;
-            if (gr >= p.M || gc >= p.N) continue;
+            if (gr >= p.M || !col_ok) continue;
             float v[8];
             {
                 const float4 v0 = *reinterpret_cast<const float4*>(slab + lr * SLAB_PITCH + ecol);
@@ -180,12 +239,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                 v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= alpha;
-            if (p.bias) {
-                const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)batch * p.sBias + gc;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bp[e];
-            }
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bv[e];
             if (mode == MD_EPI_STORE_BF16 || mode == MD_EPI_RESIDUAL) {
                 if (p.C2) {  // raw (pre-activation / pre-gate) copy for the backward pass
                     bf16x8 o;
@@ -199,10 +253,9 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
                     }
                 } else {
-                    const bf16x8 rs = ld_bf16x8(reinterpret_cast<const bf16*>(p.res) + gr * p.ldr + gc);
-                    if (p.gate) {
-                        const int64_t smp = gr / p.rows_per_sample;
-                        const bf16x8 g = ld_bf16x8(reinterpret_cast<const bf16*>(p.gate) + smp * p.ldg + gc);
+                    const bf16x8 rs = pre[mi & 1][it];
+                    if (has_gate) {
+                        const bf16x8 g = gpre[mi & 1][it];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = bf2f(rs[e]) + bf2f(g[e]) * bf2f(f2bf(v[e]));
                     } else {
@@ -215,8 +268,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
                 st_bf16x8(reinterpret_cast<bf16*>(p.C) + (int64_t)batch * p.sC + gr * p.ldc + gc, o);
             } else if (mode == MD_EPI_DACT) {
-                const bf16x8 ax =
-                    ld_bf16x8(reinterpret_cast<const bf16*>(p.aux) + (int64_t)batch * p.sAux + gr * p.ldaux + gc);
+                const bf16x8 ax = pre[mi & 1][it];
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] * apply_dact(bf2f(ax[e]), p.act));
@@ -244,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
 }
 
 template <int AKC, int BKC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_bf16_kernel(md_gemm_args p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* sA = smem;
     unsigned char* sB = smem + TILE_BYTES;
@@ -257,6 +309,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
     const int nwg = gridDim.x;
     int tile_m, tile_n;
     tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    long long* const tl = g_timeline;
+    timeline_stamp(tl, 0);
     const int64_t m0 = (int64_t)tile_m * BM;
     const int64_t n0 = (int64_t)tile_n * BN;
 
@@ -292,6 +346,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
         store_tile<AKC>(ra, sA, tid);
         store_tile<BKC>(rb, sB, tid);
         __syncthreads();
+        if (t == 0) timeline_stamp(tl, 1);
         if (t + 1 < nt) {
             const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
             load_tile<AKC>(ra, A, p.lda, m0, p.M, k0, kend, tid);
@@ -312,7 +367,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(md_gemm_args p) {
         }
     }
 
+    timeline_stamp(tl, 2);
     gemm_epilogue<2>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, batch, split, wave, lane);
+    timeline_finish(tl);
 }
 
 // =====================================================================================================================
@@ -335,8 +392,7 @@ typedef __attribute__((address_space(1))) void glb_void_t;
 // issues 4 of them per operand per tile for both supported geometries (128^2 x 4 waves, 256^2 x 8 waves).
 template <int KC, int ROWS>
 __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t rmax,
-                                         int64_t k0, int64_t kend, int wave, int lane, bool dbg_zero = false, int j0 = 0,
-                                         int j1 = 4) {
+                                         int64_t k0, int64_t kend, int wave, int lane, int j0 = 0, int j1 = 4) {
     constexpr int RPC = 512 / ROWS;       // K-strided: k-rows per 1 KiB chunk (4 or 2)
     constexpr int LPR = 64 / RPC;         // lanes (16-byte chunks) per k-row (16 or 32)
 #pragma unroll
@@ -347,12 +403,12 @@ __device__ __forceinline__ void dma_tile(unsigned char* s, const bf16* __restric
             const int row = wave * 32 + j * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int64_t gr = r0 + row, gk = k0 + c * 8;
-            src = (gr < rmax && gk < kend && !dbg_zero) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
+            src = (gr < rmax && gk < kend) ? base + gr * ld + gk : reinterpret_cast<const bf16*>(&g_zero16);
         } else {
             const int kk = (wave * 4 + j) * RPC + lane / LPR;
             const int c = (lane % LPR) ^ ((kk & 3) << 2);
             const int64_t gk = k0 + kk, gr = r0 + c * 8;
-            src = (gr < rmax && gk < kend && !dbg_zero) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
+            src = (gr < rmax && gk < kend) ? base + gk * ld + gr : reinterpret_cast<const bf16*>(&g_zero16);
         }
         __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(s + (wave * 4 + j) * 1024), 16, 0, 0);
     }
@@ -406,6 +462,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     const int nwg = gridDim.x;
     int tile_m, tile_n;
     tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
+    long long* const tl = g_timeline;
+    timeline_stamp(tl, 0);
     const int64_t m0 = (int64_t)tile_m * TM;
     const int64_t n0 = (int64_t)tile_n * TN;
     const int batch = blockIdx.y / p.ksplit;
@@ -432,86 +490,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
         dma_tile<AKC, TM>(smem, A, p.lda, m0, p.M, kbeg, kend, wave, lane);
         dma_tile<BKC, TN>(smem + ATILE, B, p.ldb, n0, p.N, kbeg, kend, wave, lane);
     }
-    const int dbg = p.debug_flags;   // ablation (timing experiments only; results are wrong when set): 1 = no in-loop DMA,
-                                     // 2 = no fragment reads after the first tile, 4 = no barriers, 8 = no epilogue, 32 = no vmcnt waits, 64 = DMA from the zero word
-    bf16x8 fa[MI], fb[2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fa[i][e] = f2bf(0.f);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fb[j][e] = f2bf(0.f);
-    if (PACED) {
-        // One barrier per tile: the DMAs of tile t+1 are issued AFTER the barrier that opens tile t (all waves are done with
-        // tile t-1, whose buffer they overwrite) and paced one chunk of each operand per k-step, instead of an 8-deep burst at
-        // the top of the loop that backs up the vector-memory queue in front of the wave's MFMAs.
-        for (int t = 0; t < nt; ++t) {
-            const int cur = t & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t has landed
-            __builtin_amdgcn_s_barrier();
-            const bool more = t + 1 < nt;
-            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
-            unsigned char* nb = smem + (cur ^ 1) * BUF;
-            const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
-#pragma unroll
-            for (int ks = 0; ks < BKT / 16; ++ks) {
-                if (more) {
-                    dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane, false, ks, ks + 1);
-                    dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane, false, ks, ks + 1);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-    } else
+    // Fragments are double-buffered in registers: the LDS reads of k-step ks+1 are issued in front of the MFMAs of k-step
+    // ks and waited for behind them, so a wave's own MFMAs cover its LDS latency (with one or two waves per SIMD nothing
+    // else does).  The reads are inline asm (see asm_read_b128); sched_barrier keeps hipcc from moving the MFMAs across
+    // the waits that guard their operands.
+    bf16x8 fa[2][MI], fb[2][2];
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt && !(dbg & 1)) {
-            const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
-            unsigned char* nb = smem + (cur ^ 1) * BUF;
-            dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane, (dbg & 64) != 0);
-            dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane, (dbg & 64) != 0);
-            if (!(dbg & 32)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
+        const bool more = t + 1 < nt;
+        const int64_t k0 = kbeg + (int64_t)(t + 1) * BKT;
+        unsigned char* nb = smem + (cur ^ 1) * BUF;
+        if (PACED) {
+            // One barrier per tile: the DMAs of tile t+1 are issued AFTER the barrier that opens tile t (all waves are done
+            // with tile t-1, whose buffer they overwrite) and paced one chunk of each operand per k-step, instead of an
+            // 8-deep burst at the top of the loop that backs up the vector-memory queue in front of the wave's MFMAs.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t has landed
+            __builtin_amdgcn_s_barrier();
         } else {
-            if (!(dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) {
+                dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane);
+                dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave's 8 DMAs); tile t+1 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                          // ... and every other wave's part of tile t
         }
-        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();           // ... and every other wave's part of tile t
+        if (t == 0) timeline_stamp(tl, 1);
         const unsigned sA = lds0 + cur * BUF, sB = sA + ATILE;
 #pragma unroll
+        for (int i = 0; i < MI; ++i) fa[0][i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, 0, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
         for (int ks = 0; ks < BKT / 16; ++ks) {
-            if (!(dbg & 2) || t == 0) {
+            const int cb = ks & 1, nx = cb ^ 1;
+            if (PACED && more) {
+                dma_tile<AKC, TM>(nb, A, p.lda, m0, p.M, k0, kend, wave, lane, ks, ks + 1);
+                dma_tile<BKC, TN>(nb + ATILE, B, p.ldb, n0, p.N, k0, kend, wave, lane, ks, ks + 1);
+            }
+            if (ks + 1 < BKT / 16) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) fa[i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks, lane);
+                for (int i = 0; i < MI; ++i) fa[nx][i] = dma_frag<AKC, TM>(sA, wm * (MI * 32) + i * 32, ks + 1, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks, lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int j = 0; j < 2; ++j) fb[nx][j] = dma_frag<BKC, TN>(sB, wn * 64 + j * 32, ks + 1, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < BKT / 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();           // buffer `cur` is free for the DMA of tile t+2
+        if (!PACED) __builtin_amdgcn_s_barrier();                  // buffer `cur` is free for the DMA of tile t+2
     }
-    if (dbg & 8) {
-        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][1] + acc[MI - 1][1][15];   // keep acc live
-        return;
-    }
+    if (PACED) __builtin_amdgcn_s_barrier();
+    timeline_stamp(tl, 2);
     gemm_epilogue<MI>(p, acc, smem, m0 + wm * (MI * 32), n0 + wn * 64, batch, split, wave, lane);
+    timeline_finish(tl);
 }
 
 // =====================================================================================================================
@@ -832,12 +872,16 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
     return 0;
 }
 
+extern "C" int md_debug_gemm_timeline(void* buf) {
+    long long* p = static_cast<long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof p);
+}
+
 extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
-    md_gemm_args a_copy = *a_in;
-    static const char* dbg_env = getenv("MD_GEMM_DEBUG");
-    a_copy.debug_flags = dbg_env ? atoi(dbg_env) : 0;
+    if (!a_in) return MD_BAD_ARG;
+    md_gemm_args a_copy = *a_in;                     // raster_group_n is filled in below
     const md_gemm_args* a = &a_copy;
-    if (!a || !a->A || !a->B || !a->C) return MD_BAD_ARG;
+    if (!a->A || !a->B || !a->C) return MD_BAD_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->ksplit <= 0) return MD_BAD_ARG;
     // All global accesses are 16-byte chunks of 8 bf16 along the contiguous dimension: leading dimensions must be
     // multiples of 8 (4 for fp32 outputs).  A contiguous extent that is not a multiple of 8 (the MoE gate: N = K =

@@ -88,7 +88,7 @@ class GemmArgs(Structure):
         ("sAux", c_int64), ("sSplit", c_int64),
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
-        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("debug_flags", c_int32), ("raster_group_n", c_int32),
+        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("reserved0", c_int32), ("raster_group_n", c_int32),
     ]
 
 
@@ -204,6 +204,7 @@ _sig("md_sumsq", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_debug_tr_probe", P, P, P)
 _sig("md_debug_mfma_probe", P, P, P, P)
+_sig("md_debug_gemm_timeline", P)
 
 
 def _declare(l: ctypes.CDLL) -> None:
