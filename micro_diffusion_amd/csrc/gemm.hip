@@ -181,7 +181,8 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
     // Every global operand of the fused ops (residual, gate, activation input, bias) is requested up front, before the
     // barrier and the LDS transpose, so their HBM round trips overlap each other and the slab traffic.  Issued one by one
     // at their point of use they serialised 8-16 dependent ~1 us loads per workgroup: the gated-residual epilogue took
-    // 18.9 k cycles against 7.5 k for the plain store (profiles/r1_gemm_timeline.txt).
+    // 18.9 k cycles against 7.5 k for the plain store, 12.8 k now (profiles/r1_gemm_timeline.txt).  Requesting them even
+    // earlier, under the last k-tile, cost more in registers than it saved (A/B: -3.5 % on the forward GEMMs).
     bf16x8 pre[2][4], gpre[2][4];      // double-buffered over mi: the set of mi + 1 is requested before mi is processed
     float bv[8];
     const bool has_pre = mode == MD_EPI_RESIDUAL || mode == MD_EPI_DACT;
@@ -554,289 +555,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     timeline_finish(tl);
 }
 
-// =====================================================================================================================
-// Ring variant: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave), k-slices of 32 streamed through a 4-stage
-// LDS ring (4 x 32 KiB) by LDS-DMA.  PMC counters on the 2-stage kernels showed the waves parked on vmcnt/barriers
-// (SQ_WAIT_ANY 37 %, MFMA busy 28 %): with one tile of prefetch the k-loop runs at memory latency (~3.2 K cycles per
-// tile vs ~1 K cycles of MFMA).  Here up to 3 stages (96 KiB) are in flight per CU, a 256^2 tile consumes half the
-// bytes per flop of a 128^2 one, ONE barrier per stage orders both the RAW (stage landed) and the WAR (buffer reuse)
-// hazards, and the per-lane DMA source pointers are computed once (per stage: one 64-bit add each).
-//   K-contiguous slice [256 rows][32 k]  (64-B rows, 16 rows per 1-KiB DMA): physical chunk = chunk ^ ((row >> 2) & 3)
-//   K-strided   slice  [32 k][256 cols]  (512-B rows, 2 rows per DMA)      : physical chunk = chunk ^ ((k & 3) << 2)
-// =====================================================================================================================
-constexpr int RK = 32;                       // k-slice depth
-constexpr int RNS = 4;                       // ring stages
-constexpr int RT = 256;                      // tile rows / columns
-constexpr int RSLICE = RT * RK * 2;          // 16 KiB per operand per stage
-constexpr int RSTAGE = 2 * RSLICE;           // 32 KiB per stage
-
-template <int KC>
-struct RingSrc {              // hoisted per-lane DMA sources of one operand: 2 DMAs per wave per stage
-    const bf16* ptr[2];       // source of k-slice 0 (or the zero word for out-of-range rows / columns)
-    int64_t step;             // element offset between consecutive k-slices
-    int kofs[2];              // k index (within a slice) this lane's 16-byte chunk starts at (K-contig) / its k-row (K-strided)
-    bool rowok[2];
-};
-
-template <int KC>
-__device__ __forceinline__ void ring_src_init(RingSrc<KC>& r, const bf16* base, int64_t ld, int64_t r0, int64_t rmax, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int chunk = wave * 2 + j;                       // 16 chunks of 1 KiB per slice
-        if (KC) {
-            const int row = chunk * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            r.rowok[j] = (r0 + row) < rmax;
-            r.kofs[j] = c * 8;
-            r.ptr[j] = base + (r0 + row) * ld + c * 8;
-        } else {
-            const int kk = chunk * 2 + (lane >> 5);
-            const int c = (lane & 31) ^ ((kk & 3) << 2);
-            r.rowok[j] = (r0 + c * 8) < rmax;
-            r.kofs[j] = kk;
-            r.ptr[j] = base + (int64_t)kk * ld + r0 + c * 8;
-        }
-    }
-    r.step = KC ? (int64_t)RK : (int64_t)RK * ld;
-}
-
-template <int KC>
-__device__ __forceinline__ void ring_dma(const RingSrc<KC>& r, unsigned char* slice, int64_t slice_idx, int64_t k0, int64_t kend, int wave) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool ok = r.rowok[j] && (k0 + r.kofs[j] < kend);
-        const bf16* src = ok ? r.ptr[j] + slice_idx * r.step : reinterpret_cast<const bf16*>(&g_zero16);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(slice + (wave * 2 + j) * 1024), 16, 0, 0);
-    }
-}
-
-template <int KC>
-__device__ __forceinline__ bf16x8 ring_frag(unsigned sbase, int row0, int ks, int lane) {
-    if (KC) {
-        const int row = row0 + (lane & 31);
-        const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
-        return asm_read_b128(sbase + row * 64 + c * 16);
-    } else {
-        const int li = lane & 15;
-        const int col = row0 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
-        const int kk = ks * 16 + (lane >> 5) * 8 + (li >> 2);
-        const int pc = (col >> 3) ^ ((kk & 3) << 2);
-        bf16x4 lo, hi;
-        asm_read_tr2<4 * RT * 2>(sbase + kk * (RT * 2) + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);
-        bf16x8 f;
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return f;
-    }
-}
-
-template <int AKC, int BKC>
-__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(md_gemm_args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RNS * RSTAGE];      // 128 KiB (epilogue slab: 8 x 8.5 KiB reuses it)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int ntn = (int)((p.N + RT - 1) / RT);
-    const int nwg = gridDim.x;
-    int tile_m, tile_n;
-    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * RT;
-    const int64_t n0 = (int64_t)tile_n * RT;
-    const int batch = blockIdx.y / p.ksplit;
-    const int split = blockIdx.y % p.ksplit;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
-    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
-    // split-K in whole 64-deep tiles (same partition as the other variants), walked in 32-deep slices
-    const int64_t ntk = (p.K + BKT - 1) / BKT;
-    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
-    const int64_t kbeg = (int64_t)split * tps * BKT;
-    int64_t kend = kbeg + tps * BKT;
-    if (kend > p.K) kend = p.K;
-    const int ns = kbeg < kend ? (int)((kend - kbeg + RK - 1) / RK) : 0;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    RingSrc<AKC> sa;
-    RingSrc<BKC> sb;
-    ring_src_init<AKC>(sa, A + (AKC ? kbeg : kbeg * p.lda), p.lda, m0, p.M, wave, lane);
-    ring_src_init<BKC>(sb, B + (BKC ? kbeg : kbeg * p.ldb), p.ldb, n0, p.N, wave, lane);
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
-
-    // prologue: slices 0 .. RNS-2 in flight
-#pragma unroll
-    for (int s = 0; s < RNS - 1; ++s) {
-        if (s < ns) {
-            ring_dma<AKC>(sa, smem + s * RSTAGE, s, kbeg + (int64_t)s * RK, kend, wave);
-            ring_dma<BKC>(sb, smem + s * RSTAGE + RSLICE, s, kbeg + (int64_t)s * RK, kend, wave);
-        }
-    }
-    for (int t = 0; t < ns; ++t) {
-        // slices issued so far: min(ns, t + RNS - 1); slice t must have landed: allow (issued - t - 1) slices x 4 DMAs
-        const int inflight = ((t + RNS - 1 < ns) ? (t + RNS - 1) : ns) - t - 1;
-        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // slice t visible to all waves; every wave is done with slice t-1 (its buffer is free)
-        const int nxt = t + RNS - 1;
-        if (nxt < ns) {
-            unsigned char* nb = smem + (nxt % RNS) * RSTAGE;
-            ring_dma<AKC>(sa, nb, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
-            ring_dma<BKC>(sb, nb + RSLICE, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
-        }
-        const unsigned sA = lds0 + (t % RNS) * RSTAGE, sB = sA + RSLICE;
-#pragma unroll
-        for (int ks = 0; ks < RK / 16; ++ks) {
-            bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = ring_frag<AKC>(sA, wm * 128 + i * 32, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = ring_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_barrier();          // all LDS reads done before the epilogue slab overwrites the ring
-    gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
-}
-
-// =====================================================================================================================
-// Ping-pong variant: the ring kernel's geometry (256 x 256 tile, 8 waves, 4-slice LDS ring of 32-deep k-slices), but the
-// two 4-wave groups (waves 0-3 / 4-7: one wave of each group on every SIMD) run HALF A PERIOD APART.  In every phase one
-// group issues its 16 MFMAs for a slice (s_setprio 1) while the other group reads the 12 fragments of its next slice and
-// issues its share of the LDS-DMA for a slice 4 ahead, so the matrix pipe of every SIMD always has a wave feeding it
-// (the lock-step kernels above leave it idle during fragment-read latency, DMA issue and barrier skew: MFMA busy 28 %).
-// One s_barrier per phase orders all hazards:
-//   RAW  slice s is read by group 0 in global phase 2s-1 and by group 1 in phase 2s; every wave waits (counted vmcnt) for
-//        its own DMAs of slice s at the end of phase 2s-2, before the barrier that opens phase 2s-1;
-//   WAR  the buffer of slice s is re-filled (slice s + 4) by group 0 in phase 2s+1 and by group 1 in phase 2s+2, i.e. after
-//        the barrier that closes phase 2s, by which both groups have drained (lgkmcnt 0) their reads of slice s.
-// Group 1 is simply group 0's program shifted by one barrier.
-// =====================================================================================================================
-__device__ __forceinline__ void wait_vm_slices(int n) {      // at most n slices (4 DMAs each) of this wave outstanding
-    if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int AKC, int BKC>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RNS * RSTAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int grp = wm;                                  // wave group = row half of the tile
-
-    const int ntn = (int)((p.N + RT - 1) / RT);
-    const int nwg = gridDim.x;
-    int tile_m, tile_n;
-    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * RT;
-    const int64_t n0 = (int64_t)tile_n * RT;
-    const int batch = blockIdx.y / p.ksplit;
-    const int split = blockIdx.y % p.ksplit;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
-    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
-    const int64_t ntk = (p.K + BKT - 1) / BKT;
-    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
-    const int64_t kbeg = (int64_t)split * tps * BKT;
-    int64_t kend = kbeg + tps * BKT;
-    if (kend > p.K) kend = p.K;
-    const int ns = kbeg < kend ? (int)((kend - kbeg + RK - 1) / RK) : 0;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[2][4], fb[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fa[ks][i][e] = f2bf(0.f);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fb[ks][j][e] = f2bf(0.f);
-    }
-
-    RingSrc<AKC> sa;
-    RingSrc<BKC> sb;
-    ring_src_init<AKC>(sa, A + (AKC ? kbeg : kbeg * p.lda), p.lda, m0, p.M, wave, lane);
-    ring_src_init<BKC>(sb, B + (BKC ? kbeg : kbeg * p.ldb), p.ldb, n0, p.N, wave, lane);
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
-
-    int issued = 0;                                     // slices whose DMA share this wave has issued
-#pragma unroll
-    for (int s = 0; s < RNS; ++s) {
-        if (s < ns) {
-            ring_dma<AKC>(sa, smem + s * RSTAGE, s, kbeg + (int64_t)s * RK, kend, wave);
-            ring_dma<BKC>(sb, smem + s * RSTAGE + RSLICE, s, kbeg + (int64_t)s * RK, kend, wave);
-            ++issued;
-        }
-    }
-    wait_vm_slices(issued - 1);                         // slice 0 landed (this wave's share)
-    __builtin_amdgcn_s_barrier();                       // opens global phase -1
-    if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 idles through phase -1
-
-    for (int q = -1; q <= 2 * ns - 2; ++q) {            // local phase; global phase P = q + grp
-        if (q & 1) {                                    // ---- load role: fragments of slice s1, DMA share of slice sd
-            const int s1 = (q + 1) >> 1;
-            if (s1 < ns) {
-                const unsigned sA = lds0 + (s1 % RNS) * RSTAGE, sB = sA + RSLICE;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[ks][i] = ring_frag<AKC>(sA, wm * 128 + i * 32, ks, lane);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[ks][j] = ring_frag<BKC>(sB, wn * 64 + j * 32, ks, lane);
-                }
-            }
-            const int sd = ((q - 1) >> 1) + RNS;
-            if (q >= 1 && sd < ns) {
-                unsigned char* nb = smem + (sd % RNS) * RSTAGE;
-                ring_dma<AKC>(sa, nb, sd, kbeg + (int64_t)sd * RK, kend, wave);
-                ring_dma<BKC>(sb, nb + RSLICE, sd, kbeg + (int64_t)sd * RK, kend, wave);
-                ++issued;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        } else {                                        // ---- compute role: slice q / 2 from the registers
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int P = q + grp;
-        if (!(P & 1)) wait_vm_slices(issued - ((P >> 1) + 2));   // slice P/2 + 1 is read in the next global phase
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();         // group 0 idles through the last phase
-    gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
-}
 
 // out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
@@ -900,17 +618,16 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     //    (measured 950-995 TFLOP/s there, but 400-500 at K = 768..1024 where nothing hides a block's prologue/epilogue);
     //  * else 128 x 128: LDS-DMA for K >= 1024 with a K-contiguous operand, register-staged (3 workgroups / CU) for
     //    short K and the TN weight-gradient shapes.
-    // MD_GEMM_VARIANT = reg | dma128 | dma256 forces one variant (A/B runs).
+    // MD_GEMM_VARIANT = reg | dma128 | dma256 | paced128 | paced256 forces one variant (A/B runs).
     static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring), 4 = pp256 (ring + wave-group ping-pong),
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage; a 4-stage ring and a wave-group ping-pong schedule were tried
+                   // and dropped: profiles/r1_gemm_pmc_ablation.txt),
                    // 5 / 6 = paced128 / paced256 (2-stage, DMA issue paced over the k-steps, one barrier per tile)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
     if (force && force[0] == 'r') variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
-    else if (force && !strcmp(force, "ring256")) variant = 3;
-    else if (force && !strcmp(force, "pp256")) variant = 4;
     else if (force && !strcmp(force, "paced128")) variant = 5;
     else if (force && !strcmp(force, "paced256")) variant = 6;
     else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
@@ -942,8 +659,6 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
     else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
     else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
-    else if (variant == 3) LAUNCH(gemm_bf16_ring_kernel, 512, );
-    else if (variant == 4) LAUNCH(gemm_bf16_pp_kernel, 512, );
     else if (variant == 5) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2 COMMA true);
     else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4 COMMA true);
 #undef COMMA
