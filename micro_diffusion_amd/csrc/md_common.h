@@ -74,31 +74,49 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Activations on the hardware transcendentals (v_exp_f32, v_rcp_f32; ~1 ulp) instead of the libm routines: the fused
+// GEMM epilogues evaluate 64-128 of them per lane, and erff / tanhf (40-50 instructions each, range-split) made the
+// MoE fc1 epilogue as long as its k-loop.  Absolute error of these forms is <= 2e-7, three orders below bf16 rounding.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// tanh(u) = 1 - 2 / (1 + e^{2u});  e^{2u} -> inf gives 1, -> 0 gives -1.
+__device__ __forceinline__ float fast_tanh(float u) { return 1.f - 2.f * fast_rcp(1.f + __expf(2.f * u)); }
+
 // tanh-approx GELU (torch.nn.GELU(approximate='tanh')) and its derivative.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.f + tanhf(u));
+    return 0.5f * x * (1.f + fast_tanh(u));
 }
 __device__ __forceinline__ float dgelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     float x2 = x * x;
     float u = k0 * (x + k1 * x * x2);
-    float t = tanhf(u);
+    float t = fast_tanh(u);
     float du = k0 * (1.f + 3.f * k1 * x2);
     return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
 }
-// exact (erf) GELU used by the expert-choice MoE (reference dit.py:124).
+// exact (erf) GELU used by the expert-choice MoE (reference dit.py:124).  Normal CDF through Abramowitz-Stegun 7.1.26
+// (|erf error| <= 1.5e-7):  Q(|x|) = 0.5 * poly(t) * exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2);  Phi(x) = x < 0 ? Q : 1 - Q
+// (no cancellation in the negative tail).  `pdf_e` returns exp(-x^2 / 2) for the derivative.
+__device__ __forceinline__ float normal_cdf_f(float x, float& pdf_e) {
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = fast_rcp(1.f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    pdf_e = __expf(-z * z);
+    const float q = 0.5f * poly * pdf_e;
+    return x < 0.f ? q : 1.f - q;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    float e;
+    return x * normal_cdf_f(x, e);
 }
 __device__ __forceinline__ float dgelu_erf_f(float x) {
-    float cdf = 0.5f * (1.f + erff(x * 0.7071067811865476f));
-    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e;
+    const float cdf = normal_cdf_f(x, e);
+    return cdf + x * 0.3989422804014327f * e;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
-    float s = 1.f / (1.f + __expf(-x));
+    float s = fast_rcp(1.f + __expf(-x));
     return s * (1.f + x * (1.f - s));
 }
