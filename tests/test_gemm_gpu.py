@@ -140,3 +140,36 @@ def test_gemm_splitk_workspace_reduce(hip):
     torch.cuda.synchronize()
     ref = 1 + torch.einsum("erd,erf->edf", X.float(), dH.float())
     assert (G - ref).abs().max() < 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0)])
+def test_gemm_many_tiles_short_k(hip, akc, bkc):
+    """Launches with >= 512 tiles of 256 x 256 and K <= 2048 take the ring kernel (256^2 tile, 4-stage LDS ring of 32-deep
+    slices): ragged M / N / K edges, gated-residual epilogue, and a grouped (batched) launch, against torch fp32 matmul."""
+    dev = "cuda"
+    torch.manual_seed(11 + akc + 2 * bkc)
+    M, N, K = 32768 + 72, 1024 + 40, 1024 + 24          # 129 x 5 = 645 tiles of 256^2, ragged in every dimension
+    A, As, lda = _mk(M, K, akc, dev)
+    B, Bs, ldb = _mk(N, K, bkc, dev, scale=0.05)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    rps = 8
+    gate = torch.randn(M // rps, N, device=dev).to(torch.bfloat16)
+    out = torch.empty_like(res)
+    hip.gemm(As, Bs, out, M, N, K, lda=lda, ldb=ldb, ldc=N, a_kcontig=akc, b_kcontig=bkc, mode=hip.EPI_RESIDUAL, res=res,
+             ldr=N, gate=gate, ldg=N, rows_per_sample=rps)
+    torch.cuda.synchronize()
+    ref = res.float() + gate.float().repeat_interleave(rps, 0) * (A.float() @ B.float().t()).to(torch.bfloat16).float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item() + 1e-3, err
+    # grouped: 8 problems x 68 tiles, K = 1024, plain bf16 store with GELU and the raw copy
+    E, R, D, F = 8, 4224, 1024, 1024
+    X = torch.randn(E, R, D, device=dev).to(torch.bfloat16)
+    W = (torch.randn(E, F, D, device=dev) * 0.03).to(torch.bfloat16)
+    H = torch.empty(E, R, F, device=dev, dtype=torch.bfloat16)
+    H2 = torch.empty_like(H)
+    hip.gemm(X, W, H, R, F, D, lda=D, ldb=D, ldc=F, a_kcontig=1, b_kcontig=1, batch=E, sA=R * D, sB=F * D, sC=R * F,
+             act=hip.ACT_GELU_ERF, C2=H2, ldc2=F, sC2=R * F)
+    torch.cuda.synchronize()
+    raw = torch.einsum("erd,efd->erf", X.float(), W.float())
+    assert (H2.float() - raw).abs().max() <= 2e-2 * raw.abs().max()
+    assert (H.float() - torch.nn.functional.gelu(raw)).abs().max() <= 2e-2 * raw.abs().max()
