@@ -555,176 +555,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     timeline_finish(tl);
 }
 
-
-// =====================================================================================================================
-// Ring variant: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave), k-slices of 32 streamed through a 4-stage
-// LDS ring (4 x 32 KiB) by LDS-DMA.  With one 64-deep tile of prefetch the k-loop of the 2-stage kernels runs at memory
-// latency when the activation operand streams from HBM (1.8 k cycles per 128^2 k-tile against 0.5-1 k of MFMA,
-// profiles/r1_gemm_timeline.txt).  Here up to 3 slices (96 KiB) are in flight per CU, multiplication starts after the
-// first 32 KiB, a 256^2 tile consumes half the bytes per flop of a 128^2 one, ONE barrier per slice orders both the RAW
-// (slice landed) and the WAR (buffer reuse) hazards, and the per-lane DMA source pointers are computed once (per slice:
-// one 64-bit add each).  Selected for K <= 2048 over many tiles; for longer contractions the 64-deep paced kernel's
-// half-as-many barriers win (profiles/r1_gemm_ring.txt).
-//   K-contiguous slice [256 rows][32 k]  (64-B rows, 16 rows per 1-KiB DMA): physical chunk = chunk ^ ((row >> 2) & 3)
-//   K-strided   slice  [32 k][256 cols]  (512-B rows, 2 rows per DMA)      : physical chunk = chunk ^ ((k & 3) << 2)
-// =====================================================================================================================
-constexpr int RK = 32;                       // k-slice depth
-constexpr int RNS = 4;                       // ring stages
-constexpr int RT = 256;                      // tile rows / columns
-constexpr int RSLICE = RT * RK * 2;          // 16 KiB per operand per stage
-constexpr int RSTAGE = 2 * RSLICE;           // 32 KiB per stage
-
-template <int KC>
-struct RingSrc {              // hoisted per-lane DMA sources of one operand: 2 DMAs per wave per stage
-    const bf16* ptr[2];       // source of k-slice 0 (or the zero word for out-of-range rows / columns)
-    int64_t step;             // element offset between consecutive k-slices
-    int kofs[2];              // k index (within a slice) this lane's 16-byte chunk starts at (K-contig) / its k-row (K-strided)
-    bool rowok[2];
-};
-
-template <int KC>
-__device__ __forceinline__ void ring_src_init(RingSrc<KC>& r, const bf16* base, int64_t ld, int64_t r0, int64_t rmax, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int chunk = wave * 2 + j;                       // 16 chunks of 1 KiB per slice
-        if (KC) {
-            const int row = chunk * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            r.rowok[j] = (r0 + row) < rmax;
-            r.kofs[j] = c * 8;
-            r.ptr[j] = base + (r0 + row) * ld + c * 8;
-        } else {
-            const int kk = chunk * 2 + (lane >> 5);
-            const int c = (lane & 31) ^ ((kk & 3) << 2);
-            r.rowok[j] = (r0 + c * 8) < rmax;
-            r.kofs[j] = kk;
-            r.ptr[j] = base + (int64_t)kk * ld + r0 + c * 8;
-        }
-    }
-    r.step = KC ? (int64_t)RK : (int64_t)RK * ld;
-}
-
-template <int KC>
-__device__ __forceinline__ void ring_dma(const RingSrc<KC>& r, unsigned char* slice, int64_t slice_idx, int64_t k0, int64_t kend, int wave) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool ok = r.rowok[j] && (k0 + r.kofs[j] < kend);
-        const bf16* src = ok ? r.ptr[j] + slice_idx * r.step : reinterpret_cast<const bf16*>(&g_zero16);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(slice + (wave * 2 + j) * 1024), 16, 0, 0);
-    }
-}
-
-template <int KC>
-__device__ __forceinline__ bf16x8 ring_frag(unsigned sbase, int row0, int ks, int lane) {
-    if (KC) {
-        const int row = row0 + (lane & 31);
-        const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
-        return asm_read_b128(sbase + row * 64 + c * 16);
-    } else {
-        const int li = lane & 15;
-        const int col = row0 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
-        const int kk = ks * 16 + (lane >> 5) * 8 + (li >> 2);
-        const int pc = (col >> 3) ^ ((kk & 3) << 2);
-        bf16x4 lo, hi;
-        asm_read_tr2<4 * RT * 2>(sbase + kk * (RT * 2) + pc * 16 + ((col >> 2) & 1) * 8, lo, hi);
-        bf16x8 f;
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return f;
-    }
-}
-
-template <int AKC, int BKC>
-__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(md_gemm_args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RNS * RSTAGE];      // 128 KiB (epilogue slab: 8 x 8.5 KiB reuses it)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int ntn = (int)((p.N + RT - 1) / RT);
-    const int nwg = gridDim.x;
-    int tile_m, tile_n;
-    tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * RT;
-    const int64_t n0 = (int64_t)tile_n * RT;
-    const int batch = blockIdx.y / p.ksplit;
-    const int split = blockIdx.y % p.ksplit;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
-    const bf16* B = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
-    // split-K in whole 64-deep tiles (same partition as the other variants), walked in 32-deep slices
-    const int64_t ntk = (p.K + BKT - 1) / BKT;
-    const int64_t tps = (ntk + p.ksplit - 1) / p.ksplit;
-    const int64_t kbeg = (int64_t)split * tps * BKT;
-    int64_t kend = kbeg + tps * BKT;
-    if (kend > p.K) kend = p.K;
-    const int ns = kbeg < kend ? (int)((kend - kbeg + RK - 1) / RK) : 0;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    RingSrc<AKC> sa;
-    RingSrc<BKC> sb;
-    ring_src_init<AKC>(sa, A + (AKC ? kbeg : kbeg * p.lda), p.lda, m0, p.M, wave, lane);
-    ring_src_init<BKC>(sb, B + (BKC ? kbeg : kbeg * p.ldb), p.ldb, n0, p.N, wave, lane);
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
-
-    // prologue: slices 0 .. RNS-2 in flight
-#pragma unroll
-    for (int s = 0; s < RNS - 1; ++s) {
-        if (s < ns) {
-            ring_dma<AKC>(sa, smem + s * RSTAGE, s, kbeg + (int64_t)s * RK, kend, wave);
-            ring_dma<BKC>(sb, smem + s * RSTAGE + RSLICE, s, kbeg + (int64_t)s * RK, kend, wave);
-        }
-    }
-    for (int t = 0; t < ns; ++t) {
-        // slices issued so far: min(ns, t + RNS - 1); slice t must have landed: allow (issued - t - 1) slices x 4 DMAs
-        const int inflight = ((t + RNS - 1 < ns) ? (t + RNS - 1) : ns) - t - 1;
-        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // slice t visible to all waves; every wave is done with slice t-1 (its buffer is free)
-        const int nxt = t + RNS - 1;
-        if (nxt < ns) {
-            unsigned char* nb = smem + (nxt % RNS) * RSTAGE;
-            ring_dma<AKC>(sa, nb, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
-            ring_dma<BKC>(sb, nb + RSLICE, nxt, kbeg + (int64_t)nxt * RK, kend, wave);
-        }
-        const unsigned sA = lds0 + (t % RNS) * RSTAGE, sB = sA + RSLICE;
-        bf16x8 fa[2][4], fb[2][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = ring_frag<AKC>(sA, wm * 128 + i * 32, 0, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = ring_frag<BKC>(sB, wn * 64 + j * 32, 0, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < RK / 16; ++ks) {
-            const int cb = ks & 1, nx = cb ^ 1;
-            if (ks + 1 < RK / 16) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[nx][i] = ring_frag<AKC>(sA, wm * 128 + i * 32, ks + 1, lane);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[nx][j] = ring_frag<BKC>(sB, wn * 64 + j * 32, ks + 1, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < RK / 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __builtin_amdgcn_s_barrier();          // all LDS reads done before the epilogue slab overwrites the ring
-    gemm_epilogue<4>(p, acc, smem, m0 + wm * 128, n0 + wn * 64, batch, split, wave, lane);
-}
-
 // out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
                                                             int64_t sOut, int ksplit, int batch, int accumulate) {
@@ -787,27 +617,28 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     //    (measured 950-995 TFLOP/s there, but 400-500 at K = 768..1024 where nothing hides a block's prologue/epilogue);
     //  * else 128 x 128: LDS-DMA for K >= 1024 with a K-contiguous operand, register-staged (3 workgroups / CU) for
     //    short K and the TN weight-gradient shapes.
-    // MD_GEMM_VARIANT = reg | dma128 | dma256 | ring256 | paced128 | paced256 forces one variant (A/B runs).
+    // MD_GEMM_VARIANT = reg | dma128 | dma256 | paced128 | paced256 forces one variant (A/B runs).
     static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage), 3 = ring256 (4-stage ring of 32-deep slices),
+    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage; a 4-stage ring, a wave-group ping-pong schedule and a persistent
+                   // tile loop were tried and dropped: profiles/r1_gemm_pmc_ablation.txt, r1_gemm_ab_epilogue.txt, r1_gemm_small_mb.txt),
                    // 5 / 6 = paced128 / paced256 (2-stage, DMA issue paced over the k-steps, one barrier per tile)
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
-    if (force && force[0] == 'r') variant = 0;
+    if (force && !strcmp(force, "reg")) variant = 0;
     else if (force && !strcmp(force, "dma128")) variant = 1;
     else if (force && !strcmp(force, "dma256")) variant = 2;
-    else if (force && !strcmp(force, "ring256")) variant = 3;
     else if (force && !strcmp(force, "paced128")) variant = 5;
     else if (force && !strcmp(force, "paced256")) variant = 6;
     else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
         variant = 6;   // weight gradients (TN): 830-1020 TFLOP/s when the caller's split-K makes ~one full round of 256 workgroups
                        // (profiles/r1_wgrad_splitk.txt), and ahead of the 128^2 kernels (600-740) at every split factor measured
-    else if (a->a_kcontig && a->ksplit == 1 && a->K <= 2048 && tiles256 >= 512)
-        variant = 3;   // ring256: short contractions over many tiles (activations x weights at large microbatches): the 32-deep
-                       // 4-stage ring starts multiplying after 32 KiB instead of 64 and keeps 96 KiB in flight: +3-10 % over the
-                       // 128^2 kernels and +19 % on the MoE fc1 shapes, but behind paced256 for K > 2048 (profiles/r1_gemm_ring.txt)
-    else if (kspan >= 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
+    else if (a->K >= 1024 && tiles256 >= 224 && tiles256 <= 256)
+        variant = 6;   // exactly one round of 256^2 workgroups (K = 1024 projections at microbatch 256: 615-628 vs 580-598 TFLOP/s)
+    else if (kspan > 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
         variant = 6;   // paced256: long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
+    else if (a->a_kcontig && a->K <= 2048)
+        variant = 0;   // activations x weights with a short contraction: the register-staged 128^2 kernel (3 workgroups / CU, compiler-
+                       // scheduled loads) leads the LDS-DMA kernels by 3-15 % at every microbatch size (profiles/r1_gemm_small_mb.txt)
     else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
     const int TMv = (variant >= 2 && variant != 5) ? 256 : 128;
     {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
@@ -832,7 +663,6 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
     else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
     else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
-    else if (variant == 3) LAUNCH(gemm_bf16_ring_kernel, 512, );
     else if (variant == 5) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2 COMMA true);
     else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4 COMMA true);
 #undef COMMA

@@ -144,8 +144,8 @@ def test_gemm_splitk_workspace_reduce(hip):
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0)])
 def test_gemm_many_tiles_short_k(hip, akc, bkc):
-    """Launches with >= 512 tiles of 256 x 256 and K <= 2048 take the ring kernel (256^2 tile, 4-stage LDS ring of 32-deep
-    slices): ragged M / N / K edges, gated-residual epilogue, and a grouped (batched) launch, against torch fp32 matmul."""
+    """Large launches (thousands of tiles, K ~ 1024) as the XL/2 microbatches produce them: ragged M / N / K edges, the
+    gated-residual epilogue, and a grouped (batched) launch with GELU + raw copy, against torch fp32 matmul."""
     dev = "cuda"
     torch.manual_seed(11 + akc + 2 * bkc)
     M, N, K = 32768 + 72, 1024 + 40, 1024 + 24          # 129 x 5 = 645 tiles of 256^2, ragged in every dimension
