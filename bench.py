@@ -205,7 +205,7 @@ def main():
         n = len(prof)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_bf16_{ring,dma,}_kernel (md_gemm_bf16 family)",
+                           "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_bf16_kernel + gemm_bf16_dma_kernel (md_gemm_bf16 family)",
                            "launches": n, "avg_launch_us": tot_ms * 1e3 / n, "gflop_per_launch": tot_fl / n / 1e9,
                            "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None}
     if rank == 0 and not args.no_cpu_baseline:
