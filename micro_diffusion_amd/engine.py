@@ -113,12 +113,12 @@ class DiTEngine:
         t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256) * batch
         out_mb = out_rows * out_cols * batch * 4 / 4e6              # microseconds to move the output once at ~4 TB/s
         best, best_cost = 1, None
-        for ks in range(1, min(64, ws_cap, max(1, contraction // 2048)) + 1):
+        for ks in range(1, min(64, ws_cap, max(1, contraction // 1024)) + 1):
             rounds = -(-t256 * ks // 256)
             cost = rounds * (contraction / ks + 1024) * 0.0335 + (2 if ks == 1 else ks + 2) * out_mb
             if best_cost is None or cost < best_cost:
                 best, best_cost = ks, cost
-        if contraction // best >= 2048 and t256 * best >= 128:
+        if contraction // best >= 1024 and t256 * best >= 128:
             return best
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * batch
         ks = max(1, self.wgrad_target_blocks // tiles)

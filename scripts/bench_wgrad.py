@@ -20,11 +20,13 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--mb", type=int, default=1024, help="microbatch the contraction lengths are scaled to (1024 = table as is)")
     a = ap.parse_args()
     L = hip.lib()
     ws = torch.empty(64 << 20, device="cuda")       # 256 MiB of fp32 slices
     print(f"# MD_GEMM_VARIANT={os.environ.get('MD_GEMM_VARIANT', '(auto)')}")
     for (M, N, K, batch, cnt) in SHAPES:
+        K = K * a.mb // 1024
         A = torch.randn(batch, K, M, device="cuda").bfloat16()
         B = torch.randn(batch, K, N, device="cuda").bfloat16()
         out = torch.zeros(batch, M, N, device="cuda")
