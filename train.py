@@ -34,9 +34,14 @@ def train(cfg: dict):
     model = mdcfg.instantiate(cfg["model"])
     model.dit.to("cuda")
     model.train()
+    carried_opt = None
     if cfg["trainer"].get("load_path"):
-        sd = torch.load(cfg["trainer"]["load_path"], map_location="cuda")
-        sd = sd.get("state", {}).get("model", sd)
+        ckpt = torch.load(cfg["trainer"]["load_path"], map_location="cuda")
+        sd = ckpt.get("state", {}).get("model", ckpt)
+        # Stage hand-off (configs/res_256_finetune.yaml:92-97): without `load_weights_only` Composer also restores the AdamW
+        # moments; the ignored keys are the stored learning rates, i.e. the new stage's lr / schedule come from ITS config.
+        if isinstance(ckpt.get("optimizer"), dict) and not cfg["trainer"].get("load_weights_only", False):
+            carried_opt = ckpt["optimizer"]
         sd = {k[len("dit."):] if k.startswith("dit.") else k: v for k, v in sd.items()}
         ignore = [k.split("/")[-1] for k in cfg["trainer"].get("load_ignore_keys", [])]
         sd = {k: v for k, v in sd.items() if not any(k == i.replace("dit.", "") for i in ignore)}
@@ -45,6 +50,11 @@ def train(cfg: dict):
     ocfg.pop("_target_")
     opt = FusedAdamW(model.dit, lr=ocfg["lr"], betas=tuple(ocfg.get("betas", (0.9, 0.999))), eps=ocfg.get("eps", 1e-8),
                      weight_decay=ocfg.get("weight_decay", 0.0))
+    if carried_opt is not None:
+        if carried_opt["m"].numel() != opt.m.numel():
+            raise RuntimeError(f"optimizer state of {cfg['trainer']['load_path']} has {carried_opt['m'].numel()} elements, "
+                               f"the model has {opt.m.numel()}")
+        opt.load_state_dict(carried_opt)
     max_ba = parse_batches(cfg["trainer"]["max_duration"])
     scfg = dict(cfg["scheduler"])
     sched = LRSchedule.from_target(scfg.pop("_target_"), t_max=max_ba, **scfg)
