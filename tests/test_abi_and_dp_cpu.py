@@ -102,3 +102,29 @@ def test_grad_buckets_cover_flat_buffer_once_gloo_ws2():
         p.join(60)
     for rank, ok, lo, hi in res:
         assert ok, f"rank {rank}: every element must be reduced exactly once (min {lo}, max {hi}, expected 3)"
+
+
+def test_splitk_factor_fills_whole_rounds():
+    """DiTEngine._ksplit (host logic, no GPU): weight-gradient GEMMs are split so that 256x256 tiles x splits make whole
+    rounds of the 256 CUs — the factors measured best on MI355X (profiles/r1_wgrad_splitk.txt) — and never exceed the
+    workspace; short contractions keep at least 512 elements per split."""
+    import types
+    from micro_diffusion_amd.engine import DiTEngine
+
+    class _WS:
+        def numel(self):
+            return 128 << 20
+    eng = types.SimpleNamespace(ws=_WS(), wgrad_target_blocks=768)
+    pick = lambda *a: DiTEngine._ksplit(eng, *a)   # noqa: E731
+    # (out_rows, out_cols, contraction, batch) -> measured-best factor at microbatch 1024 ...
+    assert pick(1024, 1024, 65536, 1) == 16        # 16 tiles x 16 = 256 workgroups
+    assert pick(2048, 1024, 78848, 1) == 8
+    assert pick(768, 768, 262144, 1) == 28         # 9 tiles x 28 = 252
+    assert pick(5376, 1024, 65536, 1) == 3         # 84 tiles x 3 = 252
+    # ... and at microbatch 256 (the per-rank shape of an 8-GPU run)
+    assert pick(1024, 1024, 16384, 1) == 16
+    assert pick(3072, 1024, 16384, 1) == 5
+    for shape in [(1024, 1024, 65536, 1), (768, 3072, 65536, 8), (16, 1024, 65536, 1), (256, 256, 1024, 1), (1024, 8, 512, 1)]:
+        ks = pick(*shape)
+        assert 1 <= ks <= 64 and ks * shape[0] * shape[1] * shape[3] <= (128 << 20)
+        assert shape[2] // ks >= 512 or ks == 1
