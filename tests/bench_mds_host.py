@@ -2,7 +2,10 @@
 native reader, next to the per-sample Python decode the reference does in its DataLoader workers (restated in
 oracle/mds_ref.py).  CPU only; shards are synthetic and page-cache resident (steady state of a multi-epoch run).
 
-    python scripts/bench_mds.py [--samples 3000] [--batch 256] [--threads 8]
+    python tests/bench_mds_host.py [--samples 3000] [--batch 256] [--threads 8]
+
+Lives under tests/ because it uses the CPU restatement (oracle/mds_ref.py) to write the synthetic shards and as the
+per-sample baseline; nothing outside tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/.
 """
 import argparse
 import os
