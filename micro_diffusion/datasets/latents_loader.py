@@ -1,1 +1,2 @@
-from micro_diffusion_amd.data import SyntheticLatents, build_streaming_latents_dataloader  # noqa: F401
+from micro_diffusion_amd.data import (LatentsLoader, StreamingLatentsDataset, SyntheticLatents,  # noqa: F401
+                                      build_streaming_latents_dataloader)
