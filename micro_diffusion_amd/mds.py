@@ -119,7 +119,11 @@ class MDSDir:
             self._L.md_mds_close(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
 
     def __len__(self):
         return self.num_samples
