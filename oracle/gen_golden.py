@@ -189,7 +189,33 @@ def gen_curve(steps=1000):
     print("tiny_curve_1k.npz")
 
 
+def gen_sampler():
+    """The reference's Heun sampler (model.py:231-297) with and without classifier-free guidance (dit.py:521-550) on the
+    tiny config: pins oracle.edm_sampler."""
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, 21)
+    dit = ref_dit_from_cfg(cfg)
+    dit.load_state_dict(sd)
+    model = ref_latent_diffusion(dit, -0.6, 1.2, 0.75)
+    model.eval()
+    batch, _, epsn, _ = orc.synth_batch(cfg, 2, 22)
+    y = batch["caption_latents"].float()
+    out = {}
+    for tag, g in (("cfg3", 3.0), ("cfg1", 1.0)):
+        x = model.edm_sampler_loop(epsn.clone(), y, steps=4, cfg=g)
+        mine = orc.edm_sampler(sd, cfg, epsn.clone(), y, 4, g)
+        err = (x - mine).abs().max().item() / x.abs().max().item()
+        assert err < 1e-3, f"oracle sampler differs from the reference ({tag}): {err}"
+        out[tag] = x.numpy()
+        print(f"sampler {tag}: max |x| {x.abs().max().item():.4f}, oracle rel err {err:.2e}")
+    np.savez_compressed(os.path.join(OUT, "tiny_sampler.npz"), **out)
+    print("tiny_sampler.npz")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sampler":
+        gen_sampler()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "curve":
         gen_curve()
         sys.exit(0)
@@ -199,3 +225,4 @@ if __name__ == "__main__":
     gen_model("tiny_mask0", orc.tiny_config(), 2, 12, 0.0, -0.6, 1.2, 77)
     gen_model("micro_mask50", micro_config(), 3, 13, 0.5, 0.0, 0.6, 20)
     gen_init()
+    gen_sampler()

@@ -105,3 +105,17 @@ def test_optimizer_restatements():
     assert orc.lr_factor("cosine_with_warmup", 0, 2500, 250000, 0.33) == 0.0
     assert abs(orc.lr_factor("cosine_with_warmup", 1250, 2500, 250000, 0.33) - 0.5) < 1e-12
     assert abs(orc.lr_factor("cosine_with_warmup", 250000, 2500, 250000, 0.33) - 0.33) < 1e-12
+
+
+@pytest.mark.parametrize("tag,guidance", [("cfg3", 3.0), ("cfg1", 1.0)])
+def test_sampler_matches_reference(tag, guidance):
+    """oracle.edm_sampler vs the reference's edm_sampler_loop (Heun, fp64 state, CFG batch-doubling; model.py:231-297,
+    dit.py:521-550) on recorded inputs.  Tolerance: fp32 round-off through 7 network evaluations at sigma up to 80."""
+    g = np.load(os.path.join(G, "tiny_sampler.npz"))
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, 21)
+    batch, _, epsn, _ = orc.synth_batch(cfg, 2, 22)
+    x = orc.edm_sampler(sd, cfg, epsn.clone(), batch["caption_latents"].float(), 4, guidance)
+    ref = torch.from_numpy(g[tag])
+    assert x.shape == ref.shape
+    assert (x - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
