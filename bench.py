@@ -208,7 +208,10 @@ def main():
                            "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_bf16_kernel + gemm_bf16_dma_kernel (md_gemm_bf16 family)",
                            "launches": n, "avg_launch_us": tot_ms * 1e3 / n, "gflop_per_launch": tot_fl / n / 1e9,
                            "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
+                               "sample": "measured at N=1 only (the other ranks would idle behind it)"}
+    elif rank == 0 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # host too small for the XL/2 oracle: report, do not fail the GPU number
