@@ -629,6 +629,7 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     else if (force && !strcmp(force, "dma256")) variant = 2;
     else if (force && !strcmp(force, "paced128")) variant = 5;
     else if (force && !strcmp(force, "paced256")) variant = 6;
+    else if (force && force[0]) return MD_BAD_ARG;   // an unknown name must not silently fall back (it once mislabelled an A/B run)
     else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
         variant = 6;   // weight gradients (TN): 830-1020 TFLOP/s when the caller's split-K makes ~one full round of 256 workgroups
                        // (profiles/r1_wgrad_splitk.txt), and ahead of the 128^2 kernels (600-740) at every split factor measured
