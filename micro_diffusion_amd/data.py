@@ -161,13 +161,28 @@ class LatentsLoader:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
         self.seed, self.depth, self.n_threads, self.loop = seed, max(2, depth), n_threads, loop
-        self.epoch = 0
+        self.epoch = 0               # epoch the next yielded batch belongs to
+        self.batch_in_epoch = 0      # batches of that epoch already yielded (resume point, see state_dict)
         per_rank = len(dataset) // self.world          # equal share per rank (tail samples rotate in with the shuffle)
         self.samples_per_rank = per_rank
         self.num_batches = per_rank // batch_size if drop_last else -(-per_rank // batch_size)
 
     def __len__(self):
         return self.num_batches
+
+    def state_dict(self) -> Dict[str, int]:
+        """Position of the consumer (what `streaming`'s StreamingDataset.state_dict gives Composer for a mid-epoch resume):
+        the order is a pure function of (seed, epoch), so (epoch, batches consumed) is the whole state."""
+        return {"epoch": self.epoch, "batch_in_epoch": self.batch_in_epoch, "seed": self.seed,
+                "batch_size": self.batch_size, "world_size": self.world}
+
+    def load_state_dict(self, sd: Dict[str, int]) -> None:
+        if (sd.get("batch_size", self.batch_size), sd.get("world_size", self.world), sd.get("seed", self.seed)) != \
+                (self.batch_size, self.world, self.seed):
+            raise ValueError(f"loader state {sd} was saved with another batch size / world size / seed")
+        self.epoch, self.batch_in_epoch = int(sd["epoch"]), int(sd["batch_in_epoch"])
+        if self.num_batches and self.batch_in_epoch >= self.num_batches:
+            self.epoch, self.batch_in_epoch = self.epoch + 1, 0
 
     def epoch_indices(self, epoch: int) -> np.ndarray:
         """Global sample ids of this rank for one epoch: a seeded permutation (identical on every rank), strided over the
@@ -192,10 +207,10 @@ class LatentsLoader:
             if self.device.type == "cuda":
                 torch.cuda.set_device(self.device)
                 copy_stream = torch.cuda.Stream(device=self.device)
-            epoch = self.epoch
+            epoch, first_b = self.epoch, self.batch_in_epoch
             while not stop.is_set():
                 idx = self.epoch_indices(epoch)
-                for b in range(self.num_batches):
+                for b in range(first_b, self.num_batches):
                     sl: _Slot = free_q.get()
                     if sl is None or stop.is_set():
                         return
@@ -214,7 +229,7 @@ class LatentsLoader:
                             sl.d_drop.copy_(sl.h_drop, non_blocking=True)
                             sl.ready.record(copy_stream)
                     ready_q.put(sl)
-                epoch += 1
+                epoch, first_b = epoch + 1, 0
                 if not self.loop:
                     break
             ready_q.put(None)
@@ -242,7 +257,6 @@ class LatentsLoader:
                     prev = None
                 item = ready_q.get()
                 if item is None:
-                    self.epoch += 1
                     return
                 if isinstance(item, BaseException):
                     raise item
@@ -255,6 +269,9 @@ class LatentsLoader:
                     batch = {"image_latents": sl.h_lat[:n].clone(), "caption_latents": sl.h_cap[:n].clone(),
                              "drop_caption_mask": sl.h_drop[:n].clone()}
                 prev = sl
+                self.batch_in_epoch += 1
+                if self.batch_in_epoch >= self.num_batches:
+                    self.epoch, self.batch_in_epoch = self.epoch + 1, 0
                 yield batch
         finally:
             stop.set()

@@ -263,3 +263,34 @@ def test_loader_coin_rate_and_reader_errors_surface(shards, tmp_path):
     assert isinstance(ld, mdata.LatentsLoader) and len(ld) == 10 and ld.dataset.cap_drop_prob == 0.1
     with pytest.raises(FileNotFoundError):
         mdata.build_streaming_latents_dataloader([d, str(tmp_path / "missing")], batch_size=5)
+
+
+def test_loader_resume_mid_epoch(shards):
+    """state_dict / load_state_dict: a loader restored from (epoch, batches consumed) continues with exactly the batches
+    (and caption-drop coins) the original would have produced, across the epoch boundary."""
+    d, _ = shards
+    ds = mdata.StreamingLatentsDataset(streams=[d], shuffle=True, image_size=256, cap_seq_size=77, cap_emb_dim=1024,
+                                       cap_drop_prob=0.2, batch_size=8)
+    a = mdata.LatentsLoader(ds, 8, device="cpu", rank=0, world_size=1, seed=9, loop=True)      # 6 batches per epoch
+    it = iter(a)
+    for _ in range(4):
+        next(it)
+    state = a.state_dict()
+    assert (state["epoch"], state["batch_in_epoch"]) == (0, 4)
+    rest = [next(it) for _ in range(5)]                                 # batches 4, 5 of epoch 0 and 0, 1, 2 of epoch 1
+    assert (a.state_dict()["epoch"], a.state_dict()["batch_in_epoch"]) == (1, 3)
+    it.close()
+    b = mdata.LatentsLoader(ds, 8, device="cpu", rank=0, world_size=1, seed=9, loop=True)
+    b.load_state_dict(state)
+    itb = iter(b)
+    for want in rest:
+        got = next(itb)
+        assert all(torch.equal(got[k], want[k]) for k in want)
+    itb.close()
+    assert b.state_dict()["epoch"] == 1 and b.state_dict()["batch_in_epoch"] == 3
+    with pytest.raises(ValueError):
+        mdata.LatentsLoader(ds, 4, device="cpu", rank=0, world_size=1, seed=9).load_state_dict(state)
+    # a state saved exactly at an epoch end resumes at the start of the next epoch
+    c = mdata.LatentsLoader(ds, 8, device="cpu", rank=0, world_size=1, seed=9)
+    c.load_state_dict({"epoch": 2, "batch_in_epoch": 6})
+    assert (c.epoch, c.batch_in_epoch) == (3, 0)

@@ -72,8 +72,22 @@ def train(cfg: dict):
     save_every = parse_batches(cfg["trainer"].get("save_interval", "0ba"))
     folder = cfg["trainer"].get("save_folder")
     log_every = int(cfg.get("misc", {}).get("log_interval", 10))
+    start = 0
+    latest = os.path.join(folder, "latest.pt") if folder else None
+    if cfg["trainer"].get("autoresume") and latest and os.path.exists(latest):
+        # Composer's autoresume: continue the run whose checkpoints live in save_folder (weights, AdamW moments, batch
+        # counter = LR-schedule position, and the data position: the loader's order is a function of (seed, epoch)).
+        ck = torch.load(latest, map_location="cuda")
+        model.dit.load_state_dict({k[len("dit."):]: v for k, v in ck["state"]["model"].items()})
+        opt.load_state_dict(ck["optimizer"])
+        start = int(ck["batch"])
+        trainer.batches_seen = start
+        if ck.get("loader") is not None and hasattr(loader, "load_state_dict"):
+            loader.load_state_dict(ck["loader"])
+        if rank == 0:
+            print(json.dumps({"resumed_from": latest, "batch": start}), flush=True)
     t_last = time.time()
-    for step, batch in zip(range(max_ba), loader):
+    for step, batch in zip(range(start, max_ba), loader):
         loss = trainer.train_step(batch)
         if not torch.isfinite(loss):                               # NaNCatcher (callbacks.py:47-64)
             raise RuntimeError(f"Train loss contains a NaN at batch {step}")
@@ -85,7 +99,9 @@ def train(cfg: dict):
         if rank == 0 and folder and save_every and (step + 1) % save_every == 0:
             os.makedirs(folder, exist_ok=True)
             torch.save({"state": {"model": {"dit." + k: v for k, v in model.dit.state_dict().items()}},
-                        "optimizer": opt.state_dict(), "batch": step + 1}, os.path.join(folder, "latest.pt"))
+                        "optimizer": opt.state_dict(), "batch": step + 1,
+                        "loader": loader.state_dict() if hasattr(loader, "state_dict") else None},
+                       os.path.join(folder, "latest.pt"))
     return trainer
 
 
