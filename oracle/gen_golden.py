@@ -213,6 +213,9 @@ def gen_sampler():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "res512":
+        gen_model("tiny512_mask75", orc.tiny512_config(), 2, 14, 0.75, 0.0, 0.6, 77)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sampler":
         gen_sampler()
         sys.exit(0)
@@ -224,5 +227,6 @@ if __name__ == "__main__":
     gen_model("tiny_mask75", orc.tiny_config(), 4, 11, 0.75, -0.6, 1.2, 77)
     gen_model("tiny_mask0", orc.tiny_config(), 2, 12, 0.0, -0.6, 1.2, 77)
     gen_model("micro_mask50", micro_config(), 3, 13, 0.5, 0.0, 0.6, 20)
+    gen_model("tiny512_mask75", orc.tiny512_config(), 2, 14, 0.75, 0.0, 0.6, 77)
     gen_init()
     gen_sampler()

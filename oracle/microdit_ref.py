@@ -79,6 +79,14 @@ def tiny_config(input_size=32) -> RefConfig:
                      ffn_multipliers=(4.0,), patch_mixer_depth=2, patch_mixer_dim=128, patch_mixer_mlp_ratio=4.0)
 
 
+def tiny512_config() -> RefConfig:
+    """configs/res_512_*.yaml geometry on the Tiny widths: 64 x 64 latents (T = 1024 tokens), pos_interp_scale = 2
+    (BASELINE.json configs[3..4] shapes)."""
+    c = tiny_config(input_size=64)
+    c.pos_interp_scale = 2.0
+    return c
+
+
 def micro_config() -> RefConfig:
     """Small config exercising branches XL/2 and Tiny do not: patch_mixer_dim == dim (Identity maps,
     dit.py:389-392), use_bias=True, split multiplier lists, 4 experts, narrow captions."""

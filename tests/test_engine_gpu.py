@@ -92,9 +92,7 @@ def test_train_step_parity(hip, tag, cfgf, B, seed, ratio, pm, ps, cap):
 
 def _res512_cfg():
     """configs/res_512_*.yaml geometry on the Tiny widths: 64x64 latents (T = 1024 tokens), pos_interp_scale = 2."""
-    c = orc.tiny_config(input_size=64)
-    c.pos_interp_scale = 2.0
-    return c
+    return orc.tiny512_config()
 
 
 @pytest.mark.parametrize("ratio", [0.75, 0.0])

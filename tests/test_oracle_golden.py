@@ -52,7 +52,8 @@ def test_pos_embed_exact():
 
 CASES = [("tiny_mask75", orc.tiny_config, 4, 11, 0.75, -0.6, 1.2, 77),
          ("tiny_mask0", orc.tiny_config, 2, 12, 0.0, -0.6, 1.2, 77),
-         ("micro_mask50", orc.micro_config, 3, 13, 0.5, 0.0, 0.6, 20)]
+         ("micro_mask50", orc.micro_config, 3, 13, 0.5, 0.0, 0.6, 20),
+         ("tiny512_mask75", orc.tiny512_config, 2, 14, 0.75, 0.0, 0.6, 77)]      # res-512 geometry, pos_interp_scale 2
 
 
 @pytest.mark.parametrize("tag,cfgf,B,seed,ratio,pm,ps,cap", CASES)
