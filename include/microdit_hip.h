@@ -10,7 +10,8 @@
  *    nothing throws across the ABI.
  *  - all memory is owned by the caller (PyTorch): arguments are raw device pointers, explicit sizes / strides
  *    in ELEMENTS as int64_t, and an explicit hipStream_t.  No allocation, no synchronisation inside.
- *  - re-entrant, no global or thread-local device state: safe to call from the autograd worker thread.
+ *  - re-entrant, no global or thread-local state on host or device (no environment reads, no device globals):
+ *    safe to call from the autograd worker thread.
  *  - "bf16" pointers are device uint16 storage of bfloat16; "f32" are float.
  */
 #ifndef MICRODIT_HIP_H
@@ -26,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MD_ABI_VERSION 1
+#define MD_ABI_VERSION 2
 int md_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM */
@@ -64,9 +65,23 @@ typedef struct md_gemm_args {
     int32_t mode; /* md_epilogue */
     int32_t act;  /* md_act */
     float alpha;
-    int32_t reserved0;      /* pass 0 */
-    int32_t raster_group_n; /* set by the library: column-tiles per L2 raster group */
+    int32_t variant;        /* md_gemm_variant; 0 = the library picks per shape (tests force each kernel) */
+    int32_t raster_group_n; /* column-tiles per L2 raster group; 0 = the library picks */
+    void* timeline;         /* profiling aid, normally NULL: every workgroup of the 2-stage kernels writes 8 int64
+                               {t_entry, t_prologue_done, t_loop_done, t_stores_drained (shader clock), wall clock
+                               (100 MHz), XCC_ID << 32 | HW_ID, 0, 0} at timeline[linear_workgroup_id * 8] */
 } md_gemm_args;
+
+/* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot
+ * run the requested problem (PP256 needs K / ksplit to be a multiple of 128, N a multiple of 8, no atomics) is
+ * rejected with -1 rather than silently replaced. */
+enum md_gemm_variant {
+    MD_GEMM_AUTO = 0,
+    MD_GEMM_REG128 = 1,   /* 128 x 128 tile, register-staged global -> LDS, 3 workgroups / CU                        */
+    MD_GEMM_DMA128 = 2,   /* 128 x 128 tile, LDS-DMA double buffer                                                   */
+    MD_GEMM_PACED256 = 3, /* 256 x 256 tile, LDS-DMA double buffer, DMA issue paced over the k-steps                 */
+    MD_GEMM_PP256 = 4     /* 256 x 256 tile, persistent, two wave groups half a phase apart, 8-slot half-tile ring   */
+};
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);
 /* out[b] (+)= sum over the ksplit dense fp32 [M, N] slices a split-K md_gemm_bf16 left in ws (deterministic). */
@@ -207,10 +222,6 @@ int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------- probes (tests only) */
 int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);
 int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream);
-/* Profiling aid: when buf != NULL every GEMM workgroup writes 8 int64 {t_entry, t_prologue_done, t_loop_done,
- * t_stores_drained (shader clock), wall clock (100 MHz), XCC_ID << 32 | HW_ID, 0, 0} at buf[linear_workgroup_id * 8];
- * NULL switches it off.  Not for production runs. */
-int md_debug_gemm_timeline(void* buf);
 
 #ifdef __cplusplus
 }

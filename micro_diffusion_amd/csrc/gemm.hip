@@ -19,13 +19,11 @@
 // Replaces the implicit cuBLAS calls behind every nn.Linear / einsum of the reference
 // (micro_diffusion/models/dit.py:84-89,131-142,224; utils.py:58-61,109-111,172-173,225-233).
 #include "md_common.h"
-#include "../../include/microdit_hip.h"
-#include <stdlib.h>
-#include <string.h>
+#include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKT = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int PITCH_KC = (BKT + 8) * 2;   // bytes per row of a K-contiguous tile  [128][64+8] bf16
 constexpr int PITCH_KS = (BM + 32) * 2;   // bytes per row of a K-strided tile     [64][128+32] bf16
 constexpr int TILE_BYTES = (BM * PITCH_KC > BKT * PITCH_KS) ? BM * PITCH_KC : BKT * PITCH_KS;  // 20480
@@ -59,11 +57,9 @@ __device__ __forceinline__ void tile_coords(int bid, int nwg, int ntn, int group
     tn = first_n + rem % gn;
 }
 
-// Optional per-workgroup timeline (md_debug_gemm_timeline): shader-clock stamps at entry, after the prologue (first tile
+// Optional per-workgroup timeline (md_gemm_args.timeline): shader-clock stamps at entry, after the prologue (first tile
 // landed), after the k-loop and after the epilogue's stores have drained, plus HW_ID (XCD / CU / SIMD placement).  Off
 // (null pointer) in normal operation; used by scripts/gemm_timeline.py to attribute a launch's time to its phases.
-__device__ long long* g_timeline = nullptr;
-
 __device__ __forceinline__ void timeline_stamp(long long* tl, int slot) {
     if (tl && threadIdx.x == 0) tl[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = clock64();
 }
@@ -150,19 +146,6 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* s, int row0, in
         f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
         return f;
     }
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == MD_ACT_GELU_TANH) return gelu_tanh_f(v);
-    if (act == MD_ACT_GELU_ERF) return gelu_erf_f(v);
-    if (act == MD_ACT_SILU) return silu_f(v);
-    return v;
-}
-__device__ __forceinline__ float apply_dact(float v, int act) {
-    if (act == MD_ACT_GELU_TANH) return dgelu_tanh_f(v);
-    if (act == MD_ACT_GELU_ERF) return dgelu_erf_f(v);
-    if (act == MD_ACT_SILU) return dsilu_f(v);
-    return 1.f;
 }
 
 // Shared epilogue: accumulators -> per-wave fp32 LDS slab -> row-contiguous 16-byte global accesses with the fused ops.
@@ -310,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nwg = gridDim.x;
     int tile_m, tile_n;
     tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
-    long long* const tl = g_timeline;
+    long long* const tl = static_cast<long long*>(p.timeline);
     timeline_stamp(tl, 0);
     const int64_t m0 = (int64_t)tile_m * BM;
     const int64_t n0 = (int64_t)tile_n * BN;
@@ -385,8 +368,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // =====================================================================================================================
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) void glb_void_t;
 
 // Tile geometry is a template parameter: ROWS = rows (or columns) of the operand tile (128 or 256), always 64 deep in K.
 // One wave-instruction moves 1 KiB: 8 rows of a K-contiguous tile, or 512/ROWS rows of a K-strided tile; every wave
@@ -463,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     const int nwg = gridDim.x;
     int tile_m, tile_n;
     tile_coords(blockIdx.x, nwg, ntn, p.raster_group_n, tile_m, tile_n);
-    long long* const tl = g_timeline;
+    long long* const tl = static_cast<long long*>(p.timeline);
     timeline_stamp(tl, 0);
     const int64_t m0 = (int64_t)tile_m * TM;
     const int64_t n0 = (int64_t)tile_n * TN;
@@ -589,11 +570,6 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
     return 0;
 }
 
-extern "C" int md_debug_gemm_timeline(void* buf) {
-    long long* p = static_cast<long long*>(buf);
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof p);
-}
-
 extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (!a_in) return MD_BAD_ARG;
     md_gemm_args a_copy = *a_in;                     // raster_group_n is filled in below
@@ -612,45 +588,40 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (a->ksplit > 1 && !(a->mode == MD_EPI_ATOMIC_F32 || (a->mode == MD_EPI_STORE_F32 && a->sSplit > 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
-    // Variant choice (measured on MI355X in the XL/2 shape mix, profiles/r1_gemm_variants.txt):
-    //  * 256 x 256 LDS-DMA tiles (8 waves, 1 workgroup / CU) only for K >= 2048 on grids that fill whole rounds of 256 CUs
-    //    (measured 950-995 TFLOP/s there, but 400-500 at K = 768..1024 where nothing hides a block's prologue/epilogue);
-    //  * else 128 x 128: LDS-DMA for K >= 1024 with a K-contiguous operand, register-staged (3 workgroups / CU) for
-    //    short K and the TN weight-gradient shapes.
-    // MD_GEMM_VARIANT = reg | dma128 | dma256 | paced128 | paced256 forces one variant (A/B runs).
-    static const char* force = getenv("MD_GEMM_VARIANT");
-    int variant;   // 0 = reg128, 1 = dma128, 2 = dma256 (2-stage; a 4-stage ring, a wave-group ping-pong schedule and a persistent
-                   // tile loop were tried and dropped: profiles/r1_gemm_pmc_ablation.txt, r1_gemm_ab_epilogue.txt, r1_gemm_small_mb.txt),
-                   // 5 / 6 = paced128 / paced256 (2-stage, DMA issue paced over the k-steps, one barrier per tile)
+    // Kernel choice.  a->variant forces one (parity tests drive every kernel on the real shapes; A/B runs); AUTO applies the
+    // rules measured on MI355X in the XL/2 shape mix (profiles/r2_gemm_variants.txt):
+    //  * PP256 (persistent ping-pong) whenever it is eligible and the launch has enough tiles to fill the chip;
+    //  * else PACED256 for weight gradients / long K on grids that make whole rounds of 256 workgroups;
+    //  * else 128 x 128: register-staged (3 workgroups / CU) for short K and TN shapes, LDS-DMA otherwise.
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
-    if (force && !strcmp(force, "reg")) variant = 0;
-    else if (force && !strcmp(force, "dma128")) variant = 1;
-    else if (force && !strcmp(force, "dma256")) variant = 2;
-    else if (force && !strcmp(force, "paced128")) variant = 5;
-    else if (force && !strcmp(force, "paced256")) variant = 6;
-    else if (force && force[0]) return MD_BAD_ARG;   // an unknown name must not silently fall back (it once mislabelled an A/B run)
-    else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
-        variant = 6;   // weight gradients (TN): 830-1020 TFLOP/s when the caller's split-K makes ~one full round of 256 workgroups
-                       // (profiles/r1_wgrad_splitk.txt), and ahead of the 128^2 kernels (600-740) at every split factor measured
-    else if (a->K >= 1024 && tiles256 >= 224 && tiles256 <= 256)
-        variant = 6;   // exactly one round of 256^2 workgroups (K = 1024 projections at microbatch 256: 615-628 vs 580-598 TFLOP/s)
-    else if (kspan > 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
-        variant = 6;   // paced256: long K amortises the un-overlapped prologue/epilogue of a 1-workgroup-per-CU kernel; avoid ragged rounds
-    else if (a->a_kcontig && a->K <= 2048)
-        variant = 0;   // activations x weights with a short contraction: the register-staged 128^2 kernel (3 workgroups / CU, compiler-
-                       // scheduled loads) leads the LDS-DMA kernels by 3-15 % at every microbatch size (profiles/r1_gemm_small_mb.txt)
-    else variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? 0 : 1;
-    const int TMv = (variant >= 2 && variant != 5) ? 256 : 128;
-    {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
+    int variant = a->variant;
+    if (variant < MD_GEMM_AUTO || variant > MD_GEMM_PP256) return MD_BAD_ARG;
+    if (variant == MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
+    if (variant == MD_GEMM_AUTO) {
+        if (md_gemm_pp_eligible(a) && tiles256 >= 192)
+            variant = MD_GEMM_PP256;
+        else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
+            variant = MD_GEMM_PACED256;   // weight gradients (TN) when the caller's split-K makes ~one full round of 256 workgroups
+        else if (a->K >= 1024 && tiles256 >= 224 && tiles256 <= 256)
+            variant = MD_GEMM_PACED256;   // exactly one round of 256^2 workgroups
+        else if (kspan > 2048 && tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 % 256 >= 160 || tiles256 >= 2048))
+            variant = MD_GEMM_PACED256;   // long K amortises the un-overlapped prologue/epilogue; avoid ragged rounds
+        else if (a->a_kcontig && a->K <= 2048)
+            variant = MD_GEMM_REG128;     // short contraction: 3 workgroups / CU hide each other's prologue / epilogue
+        else
+            variant = ((!a->a_kcontig && !a->b_kcontig) || a->K < 1024) ? MD_GEMM_REG128 : MD_GEMM_DMA128;
+    }
+    const int TMv = variant >= MD_GEMM_PACED256 ? 256 : 128;
+    if (a->raster_group_n <= 0) {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
         const int64_t ntn_ = (a->N + TMv - 1) / TMv;
         int64_t g = (2 << 20) / (TMv * kspan * 2);
-        static const char* graster = getenv("MD_GEMM_GROUP_N");
-        if (graster) g = atoi(graster);
+        if (variant == MD_GEMM_PP256 && g < 4) g = 4;   // an XCD's 32 concurrent tiles form an (32 / g) x g block
         if (g < 1) g = 1;
         if (g > ntn_) g = ntn_;
         a_copy.raster_group_n = (int)g;
     }
+    if (variant == MD_GEMM_PP256) return md_gemm_pp_launch(a, stream);
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
 #define LAUNCH(KERN, THREADS, ...)                                                                                          \
@@ -661,10 +632,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
         else hipLaunchKernelGGL((KERN<0, 0 __VA_ARGS__>), grid, dim3(THREADS), 0, stream, *a);                                     \
     } while (0)
 #define COMMA ,
-    if (variant == 0) LAUNCH(gemm_bf16_kernel, 256, );
-    else if (variant == 1) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
-    else if (variant == 2) LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4);
-    else if (variant == 5) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2 COMMA true);
+    if (variant == MD_GEMM_REG128) LAUNCH(gemm_bf16_kernel, 256, );
+    else if (variant == MD_GEMM_DMA128) LAUNCH(gemm_bf16_dma_kernel, 256, COMMA 2 COMMA 2 COMMA 2);
     else LAUNCH(gemm_bf16_dma_kernel, 512, COMMA 2 COMMA 4 COMMA 4 COMMA true);
 #undef COMMA
 #undef LAUNCH

@@ -1,0 +1,677 @@
+// Persistent ping-pong bf16 MFMA GEMM ("pp256") — the kernel the large MicroDiT linear layers run on.
+//
+//   C[m, n] (+)= alpha * sum_k A(m, k) * B(n, k)      same contract, operand layouts and epilogues as gemm.hip
+//
+// Why a second kernel family.  The 2-stage kernels of gemm.hip keep the matrix pipe busy 25-28 % of the time
+// (profiles/r1_gemm_pmc_ablation.txt): a wave reads its fragments, waits, multiplies, and every workgroup pays an
+// un-overlapped prologue and epilogue per output tile.  This kernel is built around three ideas instead:
+//
+//  1. Two wave groups per workgroup run HALF A PHASE APART (8 waves, 256 x 256 tile, one workgroup per CU, one
+//     wave of each group on every SIMD).  A k-tile (64 deep) is 4 phases; in a phase one group multiplies one
+//     64 x 32 quadrant of its 128 x 64 output (8 x v_mfma_f32_32x32x16_bf16, s_setprio 1) while the other group
+//     reads the fragments of ITS next quadrant from LDS and issues its share of the LDS-DMA prefetch, so every
+//     SIMD's matrix pipe always has one wave feeding it.  Two s_barrier per phase keep the groups in step.
+//  2. The operand tiles are staged as HALF-TILES (128 rows x 64 k, 16 KiB, two global_load_lds_dwordx4 per wave),
+//     one per phase, into a ring of 8 slots (2 k-tiles x {A0, A1, B0, B1}).  A slot is refilled two phases after its
+//     last fragment read and is read five or six phases after its DMA was issued: 4 half-tiles (64 KiB per CU) are
+//     always in flight and no s_waitcnt in the steady state ever waits for the most recent ones (vmcnt(8)).
+//  3. The workgroup is PERSISTENT: it walks a list of output tiles (XCD-aware order, see work_decode) as ONE stream
+//     of k-tiles, so the DMA prefetch of the next tile's first k-tiles runs under the last phases of the current tile
+//     and there is no per-tile prologue.  The epilogue of a finished tile is spread over the first four phases of
+//     the next tile (quadrant q is written in the load half of phase q, just before that phase's MFMAs start to
+//     re-accumulate it) and goes straight from the accumulator registers to HBM: the MFMA operands are swapped
+//     (D = B A^T) so a lane owns 4 consecutive columns of one row, v_permlane32_swap pairs them to 8, and every global
+//     access of the epilogue is 16 bytes.  Operands of fused epilogues (residual, gate, activation input, fp32
+//     accumulate) are prefetched one phase ahead with hand-counted vmcnt so they never drain the DMA ring.
+//
+// LDS image of a half-tile (the DMA writes lane-linear 1 KiB pieces, so swizzles are applied to the SOURCE address and
+// again on the fragment reads):
+//   K-contiguous operand: [128 rows][8 chunks of 16 B]   physical chunk = chunk ^ ((row >> 1) & 7)   (ds_read_b128)
+//   K-strided operand   : [ 64 k   ][16 chunks of 16 B]  physical chunk = chunk ^ ((k & 3) << 2)     (ds_read_b64_tr_b16)
+// Rows / columns beyond M / N are CLAMPED to the last valid one (they only feed outputs that are never stored).
+//
+// Requirements (md_gemm_bf16 falls back to the gemm.hip kernels otherwise): K per split a multiple of 128.
+//
+// Replaces the implicit cuBLAS calls behind every large nn.Linear / einsum of the reference
+// (micro_diffusion/models/dit.py:84-89,131-142,224; utils.py:58-61,109-111,172-173,225-233) and their backward.
+#include "md_common.h"
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PT = 256;            // output tile rows / columns
+constexpr int HT = 16384;          // bytes of one half-tile
+constexpr int B_REGION = 65536;    // A slots live in [0, 64 KiB), B slots in [64 KiB, 128 KiB): slot(b, h) = b * 32768 + h * 16384
+constexpr int NUM_CU = 256;        // MI355X
+
+template <int KC>
+struct Frag;
+template <>
+struct Frag<1> {
+    bf16x8 v;
+    __device__ __forceinline__ bf16x8 get() const { return v; }
+};
+template <>
+struct Frag<0> {
+    bf16x4 lo, hi;
+    __device__ __forceinline__ bf16x8 get() const {
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+};
+
+// Fragment reads are inline asm: hipcc puts a full vmcnt(0) in front of every LDS read it can see while an LDS-DMA is
+// pending.  Their destinations are "pinned" after the caller's lgkmcnt(0) (frag_pin: an empty asm that re-defines the
+// registers), so no copy of a destination can be scheduled before the data has landed.
+template <int KC, int OFF>
+__device__ __forceinline__ void frag_read(Frag<KC>& f, unsigned addr) {
+    static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds offset field is 16 bits");
+    if constexpr (KC) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(addr), "i"(OFF) : "memory");
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(f.lo), "=&v"(f.hi)
+                     : "v"(addr), "i"(OFF), "i"(OFF + 1024)
+                     : "memory");
+    }
+}
+template <int KC>
+__device__ __forceinline__ void frag_pin(Frag<KC>& f) {
+    if constexpr (KC) asm volatile("" : "+v"(f.v));
+    else asm volatile("" : "+v"(f.lo), "+v"(f.hi));
+}
+
+// Per-lane LDS byte addresses of the fragment reads (computed once).
+//  K-contiguous: ad[ks] (k-step 0..3); the row-fragment index i is an immediate (i * 4096).
+//  K-strided   : ad[i]  (row-fragment 0..1); the k-step is an immediate (ks * 4096).
+// row0 = first row (column) of this wave's 64- (A) or 32- (B) wide strip inside the 128-wide half-tile.
+template <int KC>
+__device__ __forceinline__ void frag_addrs(unsigned (&ad)[4], unsigned base, int row0, int lane) {
+    if constexpr (KC) {
+        const int r = row0 + (lane & 31);
+        ad[0] = base + r * 128 + ((((lane >> 5) ^ (r >> 1)) & 7) << 4);   // k-step ks: chunk (2 ks + hi) ^ s == (hi ^ s) ^ 2 ks,
+        ad[1] = ad[2] = ad[3] = 0;                                        // i.e. ad[0] ^ (ks << 5)
+    } else {
+        const int li = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = row0 + i * 32 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+            const int kk = (lane >> 5) * 8 + (li >> 2);
+            const int pc = (col >> 3) ^ ((kk & 3) << 2);
+            ad[i] = base + kk * 256 + pc * 16 + ((col >> 2) & 1) * 8;
+        }
+        ad[2] = ad[3] = 0;
+    }
+}
+template <int KC, int SLOT, int I, int KS>
+__device__ __forceinline__ void frag_read_at(Frag<KC>& f, const unsigned (&ad)[4], int kx32) {
+    // kx32 = 32 hidden behind an asm so that ad[0] ^ (KS * 32) is recomputed at the read (one v_xor) instead of living in
+    // three more registers per operand for the whole kernel
+    if constexpr (KC) frag_read<KC, SLOT + I * 4096>(f, KS == 0 ? ad[0] : (ad[0] ^ (unsigned)(KS * kx32)));
+    else frag_read<KC, SLOT + KS * 4096>(f, ad[I]);
+}
+
+// Per-lane byte offsets (relative to the tile's base pointer) of the two 1 KiB DMA pieces this wave contributes to each
+// half-tile h of an operand whose tile starts at row r0 (rmax rows in total).
+template <int KC>
+__device__ __forceinline__ void stage_offsets(unsigned (&ofs)[2][2], int r0, int rmax, int ld, int wave, int lane) {
+    asm volatile("" : "+v"(lane));     // evaluated once per output tile: keep its lane-derived sub-terms out of the loop-invariant registers
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (KC) {
+                const int row = (wave * 2 + j) * 8 + (lane >> 3);            // row inside the half-tile
+                const int c = (lane & 7) ^ ((row >> 1) & 7);                  // logical 16-byte chunk this lane fetches
+                int gr = r0 + h * 128 + row;
+                gr = (gr < rmax ? gr : rmax - 1) - r0;
+                ofs[h][j] = (unsigned)(gr * ld + c * 8) * 2u;
+            } else {
+                const int kk = (wave * 2 + j) * 4 + (lane >> 4);
+                const int c = (lane & 15) ^ ((kk & 3) << 2);
+                int gc = r0 + h * 128 + c * 8;
+                const int last = (rmax - 1) & ~7;
+                gc = (gc < last ? gc : last) - r0;
+                ofs[h][j] = (unsigned)(kk * ld + gc) * 2u;
+            }
+        }
+}
+
+__device__ __forceinline__ void stage_half(const char* base, const unsigned (&ofs)[2], unsigned char* slot, int wave) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + ofs[j]), (lds_void_t*)(slot + (wave * 2 + j) * 1024), 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Work list.  W = tiles x batch x ksplit items; XCD x (workgroups with blockIdx % 8 == x share an L2) owns a contiguous
+// range of item ids, and its workgroups take consecutive ids in every round, so the ~32 tiles an XCD works on at any
+// time form a (32 / group_n) x group_n block of the output that shares A row-panels and B column-panels in L2.
+// The plan is computed on the host (md_gemm_pp_launch) and passed by value.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PPPlan {
+    int ntm, ntn, ntiles, total;   // tiles per problem; items in total
+    int nk;                        // k-tiles (64 deep) per item, even
+    int kspan;                     // elements of K per split
+    int group_n;                   // column-tiles per raster group
+    int M, N, ksplit;
+    int lda, ldb;
+};
+
+__device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
+    const unsigned y = (unsigned)item / (unsigned)w.ntiles;
+    const unsigned t = (unsigned)item - y * (unsigned)w.ntiles;
+    batch = (int)(y / (unsigned)w.ksplit);
+    split = (int)(y - (unsigned)batch * (unsigned)w.ksplit);
+    const unsigned per_group = (unsigned)(w.group_n * w.ntm);
+    const unsigned g = t / per_group, rem = t - g * per_group;
+    const int first_n = (int)g * w.group_n;
+    const int gn = (w.ntn - first_n) < w.group_n ? (w.ntn - first_n) : w.group_n;
+    const unsigned tm = rem / (unsigned)gn;
+    m0 = (int)tm * PT;
+    n0 = (first_n + (int)(rem - tm * (unsigned)gn)) * PT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of one 64 x 32 quadrant (2 row-fragments of 32 x 32) of one wave.
+// After the operand swap a lane holds C[row = lane & 31][8 g + 4 hi + e] in acc[4 g + e] (hi = lane >> 5); swapping the
+// register groups (2 pp, 2 pp + 1) between the half-waves leaves 8 consecutive columns (16 pp + 8 hi ..) per lane.
+// The epilogue kind is a template parameter (one kernel per kind): with the mode and the activation as run-time values
+// every one of the eight inlined copies carried all the branches (65 k instructions per kernel).
+// ---------------------------------------------------------------------------------------------------------------------
+enum {
+    PP_E_BF16 = 0,       // MD_EPI_STORE_BF16, no activation            (+ bias, + C2)
+    PP_E_BF16_GELU = 1,  // MD_EPI_STORE_BF16, GELU(erf)                (+ bias, + C2: the MoE fc1)
+    PP_E_RES = 2,        // MD_EPI_RESIDUAL                             (+ bias, + gate, + C2)
+    PP_E_DACT_GELU = 3,  // MD_EPI_DACT through GELU(erf)               (the MoE fc1 dgrad)
+    PP_E_F32 = 4         // MD_EPI_STORE_F32                            (+ bias; split-K slices)
+    // MD_EPI_ACCUM_F32 stays on the gemm.hip kernels: its operand (32 fp32 per lane and quadrant) does not fit beside the
+    // fragments, and without the one-phase-ahead prefetch each quadrant would drain the DMA ring.
+};
+
+struct EpiTile {
+    int m0, n0, batch, split;
+};
+
+__device__ __forceinline__ uint4 asm_load16(const void* ptr) {
+    uint4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+template <int EPI>
+__device__ __forceinline__ int epi_prefetch_count(const md_gemm_args& p) {
+    if (EPI == PP_E_RES) return p.gate ? 6 : 4;
+    if (EPI == PP_E_DACT_GELU) return 4;
+    return 0;
+}
+
+// Lane geometry of the epilogue: rl / cl = row / column inside the 256 x 256 tile of element block (i = 0, pp = 0) of
+// quadrant (0, 0); block (IH, JH, i, pp) adds (IH * 128 + i * 32) rows and (JH * 128 + pp * 16) columns.
+struct EpiLane {
+    int lane, wrow, wcol;   // wrow = wr * 64, wcol = wc * 32: this wave's strip inside a 128-wide half (wave-uniform)
+    // rl / cl are recomputed from the lane id at every use (behind an asm, so they are not hoisted into loop-invariant
+    // registers): every VGPR that lives across the main loop is one the fragment / prefetch registers cannot have.
+    __device__ __forceinline__ void coords(int& rl, int& cl) const {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        rl = wrow + (l & 31);
+        cl = wcol + (l >> 5) * 8;
+    }
+};
+
+// All epilogue addresses are  uniform 64-bit base of the tile (SGPRs)  +  32-bit per-lane byte offset  (one VGPR each,
+// global_* saddr form): ptr + batch stride + m0 * ld + n0, and (row_in_tile * ld + col_in_tile) * element size.
+__device__ __forceinline__ const char* tile_base(const void* ptr, int64_t batch_off, const EpiTile& et, int64_t ld, int esize) {
+    return reinterpret_cast<const char*>(ptr) + (batch_off + (int64_t)et.m0 * ld + et.n0) * esize;
+}
+__device__ __forceinline__ unsigned lane_off(int r, int c, int ld, int esize) { return (unsigned)(r * ld + c) * (unsigned)esize; }
+
+// Operands of quadrant (IH, JH), requested one phase ahead.  Rows / columns are clamped into the matrix so every lane
+// issues every load (the counted waits rely on exact instruction counts).
+//   residual: pre[i * 2 + pp]; gate: pre[4 + pp] (rows_per_sample is a multiple of 64, so the 64 rows of a quadrant share one
+//   gate row); activation input: pre[i * 2 + pp].
+template <int EPI, int IH, int JH>
+__device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan& w, const EpiTile& et, uint4 (&pre)[6],
+                                             const EpiLane& el) {
+    const int mlast = w.M - 1 - et.m0;                               // last valid row / first column of the last chunk, tile-relative
+    const int nlast = ((w.N - 1) & ~7) - et.n0;
+    int rl, cl;
+    el.coords(rl, cl);
+    const char* base = EPI == PP_E_RES ? tile_base(p.res, 0, et, p.ldr, 2) : tile_base(p.aux, (int64_t)et.batch * p.sAux, et, p.ldaux, 2);
+    const int ld = EPI == PP_E_RES ? (int)p.ldr : (int)p.ldaux;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            int r = rl + IH * 128 + i * 32, c = cl + JH * 128 + pp * 16;
+            r = r < mlast ? r : mlast;
+            c = c < nlast ? c : nlast;
+            pre[i * 2 + pp] = asm_load16(base + lane_off(r, c, ld, 2));
+        }
+    if (EPI == PP_E_RES && p.gate) {
+        int r0 = et.m0 + IH * 128 + el.wrow;                          // wave-uniform: the quadrant's first row
+        r0 = r0 < w.M - 1 ? r0 : w.M - 1;
+        const char* g = reinterpret_cast<const char*>(p.gate) +
+                        ((int64_t)((unsigned)r0 / (unsigned)p.rows_per_sample) * p.ldg + et.n0) * 2;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            int c = cl + JH * 128 + pp * 16;
+            c = c < nlast ? c : nlast;
+            pre[4 + pp] = asm_load16(g + (unsigned)c * 2u);
+        }
+    }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(w[e] << 16);
+        f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    U128 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
+    return t.u;
+}
+__device__ __forceinline__ float bf_round(float v) { return bf2f(f2bf(v)); }
+
+template <int EPI, int IH, int JH>
+__device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et,
+                                             const uint4 (&pre)[6], const EpiLane& el) {
+    const float alpha = p.alpha;
+    const int mlim = w.M - et.m0, nlim = w.N - et.n0;
+    constexpr bool F32OUT = (EPI == PP_E_F32);
+    constexpr int ES = F32OUT ? 4 : 2;
+    char* cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.batch * p.sC + (F32OUT ? (int64_t)et.split * p.sSplit : 0), et, p.ldc, ES));
+    const int ldc = (int)p.ldc;
+    int rl, cl;
+    el.coords(rl, cl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int r = rl + IH * 128 + i * 32, c = cl + JH * 128 + pp * 16;
+            const bool ok = r < mlim && c < nlim;
+            const int x = i * 2 + pp;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // vdst = group 2 pp, src = group 2 pp + 1: lanes 0-31 end with [own g0 | upper's g0], lanes 32-63 with
+                // [lower's g1 | own g1]
+                const unsigned a = __float_as_uint(acc[i][8 * pp + e]);
+                const unsigned b = __float_as_uint(acc[i][8 * pp + 4 + e]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                v[e] = __uint_as_float(sw[0]) * alpha;
+                v[4 + e] = __uint_as_float(sw[1]) * alpha;
+            }
+            if (EPI != PP_E_DACT_GELU && p.bias && ok) {
+                const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + c;
+                const float4 b0 = *reinterpret_cast<const float4*>(bp);
+                const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (!F32OUT) {
+                if (EPI != PP_E_DACT_GELU && p.C2 && ok) {
+                    char* c2 = const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2));
+                    *reinterpret_cast<uint4*>(c2 + lane_off(r, c, (int)p.ldc2, 2)) = pack8(v);
+                }
+                if (EPI == PP_E_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 4; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (EPI == PP_E_RES) {
+                    float rs[8];
+                    unpack8(pre[x], rs);
+                    if (p.gate) {
+                        float g[8];
+                        unpack8(pre[4 + pp], g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rs[e] + g[e] * bf_round(v[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rs[e] + bf_round(v[e]);
+                    }
+                } else if (EPI == PP_E_DACT_GELU) {
+                    float ax[8];
+                    unpack8(pre[x], ax);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_f(ax[e]);
+                    __builtin_amdgcn_sched_barrier(0);            // two batches of four: eight interleaved evaluations spill
+#pragma unroll
+                    for (int e = 4; e < 8; ++e) v[e] *= dgelu_erf_f(ax[e]);
+                }
+                if (ok) *reinterpret_cast<uint4*>(cbase + lane_off(r, c, ldc, 2)) = pack8(v);
+            } else {
+                if (ok) {
+                    float* cp = reinterpret_cast<float*>(cbase + lane_off(r, c, ldc, 4));
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+template <int AKC, int BKC, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPlan w) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * B_REGION];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;      // wave group = wr; rows wr * 64 .. of each A half, columns wc * 32 .. of each B half
+
+    // ---- this workgroup's share of the work list
+    int w_first, w_stride, w_count;
+    {
+        const int G = gridDim.x, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = w.total >> 3, r = w.total & 7;
+        const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = q + (x < r ? 1 : 0);
+        w_stride = (G - x + 7) >> 3;               // workgroups on this XCD
+        w_first = lo + j;
+        w_count = j < cnt ? (int)((unsigned)(cnt - j + w_stride - 1) / (unsigned)w_stride) : 0;
+    }
+    if (w_count == 0) return;
+    const int half_iters = w_count * (w.nk >> 1);  // loop iterations: two k-tiles each
+
+    // ---- per-lane constants
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+    unsigned adA[4], adB[4];
+    frag_addrs<AKC>(adA, lds0, wr * 64, lane);
+    frag_addrs<BKC>(adB, lds0 + B_REGION, wc * 32, lane);
+    const int64_t a_kstep = AKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.lda * 2;   // bytes per k-tile
+    const int64_t b_kstep = BKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.ldb * 2;
+    const EpiLane el = {lane, wr * 64, wc * 32};
+
+    // ---- stager (DMA prefetch) cursor
+    int s_n = 0, s_kt = 0;                         // item ordinal, k-tile inside the item
+    bool s_live = true;
+    const char *sA = nullptr, *sB = nullptr;       // uniform base pointers of the stager's current k-tile
+    unsigned aofs[2][2], bofs[2][2];
+    auto stager_open = [&](int n) {                // point the stager at item ordinal n
+        int m0, n0, batch, split;
+        work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
+        const int64_t kbeg = (int64_t)split * w.kspan;
+        const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+        const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+        sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)m0 * w.lda + kbeg : Ab + kbeg * w.lda + m0);
+        sB = reinterpret_cast<const char*>(BKC ? Bb + (int64_t)n0 * w.ldb + kbeg : Bb + kbeg * w.ldb + n0);
+        stage_offsets<AKC>(aofs, m0, w.M, w.lda, wave, lane);
+        stage_offsets<BKC>(bofs, n0, w.N, w.ldb, wave, lane);
+    };
+    auto stager_advance = [&]() {                  // after the last half-tile (A1) of a k-tile
+        sA += a_kstep;
+        sB += b_kstep;
+        if (++s_kt == w.nk) {
+            s_kt = 0;
+            if (++s_n < w_count) stager_open(s_n);
+            else s_live = false;
+        }
+    };
+    // KIND: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (the order they are consumed in); BUF = k-tile parity
+#define PP_STAGE(KIND, BUF)                                                                                             \
+    do {                                                                                                                \
+        if (s_live) {                                                                                                   \
+            if (KIND == 0) stage_half(sA, aofs[0], smem + (BUF) * 32768, wave);                                         \
+            else if (KIND == 1) stage_half(sB, bofs[0], smem + B_REGION + (BUF) * 32768, wave);                         \
+            else if (KIND == 2) stage_half(sB, bofs[1], smem + B_REGION + (BUF) * 32768 + HT, wave);                    \
+            else { stage_half(sA, aofs[1], smem + (BUF) * 32768 + HT, wave); stager_advance(); }                        \
+        }                                                                                                               \
+    } while (0)
+
+    // ---- compute cursor / epilogue state
+    int c_n = 0, c_kt = 0;
+    bool epi_pending = false;
+    int pf_after = 0;                              // DMA instructions issued after the pending operand prefetch
+    EpiTile et = {0, 0, 0, 0};
+    const int npf = epi_prefetch_count<EPI>(p);
+    const bool has_ops = npf > 0;
+    uint4 pre[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) pre[x] = make_uint4(0, 0, 0, 0);
+
+    f32x16 acc[4][2];                              // quadrant q = ih * 2 + jh, row-fragment i
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
+    Frag<AKC> fa[2][4];                            // [row-fragment][k-step] of the current A half
+    Frag<BKC> fb0[4], fb1[4];                      // [k-step] of B half 0 / 1
+
+    // ---- prologue: k-tile 0 complete, k-tile 1's A0 / B0
+    stager_open(0);
+    PP_STAGE(0, 0); PP_STAGE(1, 0); PP_STAGE(2, 0); PP_STAGE(3, 0);
+    PP_STAGE(0, 1); PP_STAGE(1, 1);
+    PP_VMCNT(8);                                   // A0, B0 of k-tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
+
+#define PP_READ_A(BUF, IH)                                                                                              \
+    do {                                                                                                                \
+        frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 0, 0>(fa[0][0], adA, kx32); frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 1, 0>(fa[1][0], adA, kx32); \
+        frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 0, 1>(fa[0][1], adA, kx32); frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 1, 1>(fa[1][1], adA, kx32); \
+        frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 0, 2>(fa[0][2], adA, kx32); frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 1, 2>(fa[1][2], adA, kx32); \
+        frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 0, 3>(fa[0][3], adA, kx32); frag_read_at<AKC, (BUF) * 32768 + (IH) * HT, 1, 3>(fa[1][3], adA, kx32); \
+    } while (0)
+#define PP_READ_B(FB, BUF, JH)                                                                                          \
+    do {                                                                                                                \
+        frag_read_at<BKC, (BUF) * 32768 + (JH) * HT, 0, 0>(FB[0], adB, kx32); frag_read_at<BKC, (BUF) * 32768 + (JH) * HT, 0, 1>(FB[1], adB, kx32); \
+        frag_read_at<BKC, (BUF) * 32768 + (JH) * HT, 0, 2>(FB[2], adB, kx32); frag_read_at<BKC, (BUF) * 32768 + (JH) * HT, 0, 3>(FB[3], adB, kx32); \
+    } while (0)
+#define PP_PIN_A()                                                                                                      \
+    do {                                                                                                                \
+        frag_pin<AKC>(fa[0][0]); frag_pin<AKC>(fa[1][0]); frag_pin<AKC>(fa[0][1]); frag_pin<AKC>(fa[1][1]);             \
+        frag_pin<AKC>(fa[0][2]); frag_pin<AKC>(fa[1][2]); frag_pin<AKC>(fa[0][3]); frag_pin<AKC>(fa[1][3]);             \
+    } while (0)
+#define PP_PIN_B(FB)                                                                                                    \
+    do { frag_pin<BKC>(FB[0]); frag_pin<BKC>(FB[1]); frag_pin<BKC>(FB[2]); frag_pin<BKC>(FB[3]); } while (0)
+    // D = B A^T: first operand = the B fragment (its 32 "rows" are output columns), second = the A fragment
+#define PP_MFMA(Q, FB)                                                                                                  \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+            const bf16x8 bq = FB[ks].get();                                                                             \
+            acc[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[0][ks].get(), acc[Q][0], 0, 0, 0);               \
+            acc[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[1][ks].get(), acc[Q][1], 0, 0, 0);               \
+        }                                                                                                               \
+    } while (0)
+    // The load half of an epilogue phase: operands of this quadrant ready -> write it -> prefetch the next quadrant's.
+#define PP_EPI(IH, JH, Q, NIH, NJH, HAS_NEXT)                                                                           \
+    do {                                                                                                                \
+        if (epi_pending) {                                                                                              \
+            if (has_ops) { if (pf_after) PP_VMCNT(2); else PP_VMCNT(0); }                                               \
+            epi_quadrant<EPI, IH, JH>(p, w, acc[Q], et, pre, el);                                                     \
+            if (HAS_NEXT) { if (has_ops) { epi_prefetch<EPI, NIH, NJH>(p, w, et, pre, el); pf_after = 0; } }         \
+            else epi_pending = false;                                                                                   \
+        }                                                                                                               \
+    } while (0)
+    // RAW guard of the DMA ring: the half-tile issued 4 phases ago has landed (8 younger DMA instructions may be pending).
+    // In an epilogue phase with prefetched operands the operand wait at its top has already proven that (loads complete
+    // in order) and a count of 8 here would wait for the prefetch just issued.
+#define PP_RAW_WAIT(EPI_PHASE)                                                                                          \
+    do {                                                                                                                \
+        if (!((EPI_PHASE) && has_ops && epi_was)) { if (s_live) PP_VMCNT(8); else PP_VMCNT(0); }                        \
+    } while (0)
+#define PP_PIN_NONE() do { } while (0)
+#define PP_COMPUTE(Q, FB, PINS)                                                                                         \
+    do {                                                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        PINS;                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        PP_MFMA(Q, FB);                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+    } while (0)
+
+    for (int it = 0; it < half_iters; ++it) {
+        const bool last_pair = (c_kt + 2 == w.nk);
+        int kx32 = 32;
+        asm volatile("" : "+s"(kx32));
+        bool epi_was;
+        // ================= k-tile in buffer 0 =================
+        // phase 1: quadrant (0, 0) <- A0 B0
+        epi_was = epi_pending;
+        PP_EPI(0, 0, 0, 0, 1, true);
+        PP_READ_B(fb0, 0, 0); PP_READ_A(0, 0);
+        PP_STAGE(2, 1); if (s_live) pf_after = 2;
+        PP_RAW_WAIT(true);
+        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A());
+        // phase 2: quadrant (0, 1) <- A0 B1
+        epi_was = epi_pending;
+        PP_EPI(0, 1, 1, 1, 1, true);
+        PP_READ_B(fb1, 0, 1);
+        { const bool live = s_live; PP_STAGE(3, 1); if (live) pf_after = 2; }
+        PP_RAW_WAIT(true);
+        PP_COMPUTE(1, fb1, PP_PIN_B(fb1));
+        // phase 3: quadrant (1, 1) <- A1 B1
+        epi_was = epi_pending;
+        PP_EPI(1, 1, 3, 1, 0, true);
+        PP_READ_A(0, 1);
+        PP_STAGE(0, 0); if (s_live) pf_after = 2;
+        PP_RAW_WAIT(true);
+        PP_COMPUTE(3, fb1, PP_PIN_A());
+        // phase 4: quadrant (1, 0) <- A1 B0
+        epi_was = epi_pending;
+        PP_EPI(1, 0, 2, 0, 0, false);
+        PP_STAGE(1, 0);
+        PP_RAW_WAIT(true);
+        PP_COMPUTE(2, fb0, PP_PIN_NONE());
+        // ================= k-tile in buffer 1 =================
+        epi_was = false;
+        PP_READ_B(fb0, 1, 0); PP_READ_A(1, 0);
+        PP_STAGE(2, 0);
+        PP_RAW_WAIT(false);
+        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A());
+        PP_READ_B(fb1, 1, 1);
+        PP_STAGE(3, 0);
+        PP_RAW_WAIT(false);
+        PP_COMPUTE(1, fb1, PP_PIN_B(fb1));
+        PP_READ_A(1, 1);
+        PP_STAGE(0, 1);
+        PP_RAW_WAIT(false);
+        PP_COMPUTE(3, fb1, PP_PIN_A());
+        // phase 8: on the last k-tile pair of an output tile, request the operands of the first epilogue quadrant
+        if (last_pair) {
+            work_decode(w, w_first + c_n * w_stride, et.m0, et.n0, et.batch, et.split);
+            if (has_ops) epi_prefetch<EPI, 0, 0>(p, w, et, pre, el);
+        }
+        {
+            const bool live = s_live;
+            PP_STAGE(1, 1);
+            pf_after = live ? 2 : 0;
+            if (last_pair && has_ops) {
+                // exact count: the 8 younger DMA instructions plus the operand loads just issued are all loads (in order)
+                if (!live) PP_VMCNT(0);
+                else if (npf == 6) PP_VMCNT(14);
+                else PP_VMCNT(12);
+            } else {
+                if (live) PP_VMCNT(8); else PP_VMCNT(0);
+            }
+        }
+        PP_COMPUTE(2, fb0, PP_PIN_NONE());
+        c_kt += 2;
+        if (last_pair) { c_kt = 0; ++c_n; epi_pending = true; }
+    }
+    // ---- drain: the last tile's accumulators
+    if (wr == 0) __builtin_amdgcn_s_barrier();     // pairs with group 1's extra barrier at the start
+    PP_VMCNT(0);
+    if (has_ops) { /* quadrant (0, 0)'s operands were requested in the last phase 8 */ }
+    epi_quadrant<EPI, 0, 0>(p, w, acc[0], et, pre, el);
+    if (has_ops) { epi_prefetch<EPI, 0, 1>(p, w, et, pre, el); PP_VMCNT(0); }
+    epi_quadrant<EPI, 0, 1>(p, w, acc[1], et, pre, el);
+    if (has_ops) { epi_prefetch<EPI, 1, 1>(p, w, et, pre, el); PP_VMCNT(0); }
+    epi_quadrant<EPI, 1, 1>(p, w, acc[3], et, pre, el);
+    if (has_ops) { epi_prefetch<EPI, 1, 0>(p, w, et, pre, el); PP_VMCNT(0); }
+    epi_quadrant<EPI, 1, 0>(p, w, acc[2], et, pre, el);
+}
+
+}  // namespace
+
+static int pp_epi_kind(const md_gemm_args* a) {
+    switch (a->mode) {
+        case MD_EPI_STORE_BF16: return a->act == MD_ACT_NONE ? PP_E_BF16 : a->act == MD_ACT_GELU_ERF ? PP_E_BF16_GELU : -1;
+        case MD_EPI_RESIDUAL: return PP_E_RES;
+        case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? PP_E_DACT_GELU : -1;
+        case MD_EPI_STORE_F32: return PP_E_F32;
+        default: return -1;
+    }
+}
+
+// Layout x epilogue combinations that are instantiated = the ones the MicroDiT engine launches at sizes that fill the chip:
+//   NT (activations x torch weights): bf16, residual, dact(gelu)   NN (dgrads, MoE experts): bf16, bf16+gelu, residual, f32
+//   TN (weight gradients): f32 slices
+static bool pp_instantiated(int akc, int bkc, int epi) {
+    if (akc && bkc) return epi == PP_E_BF16 || epi == PP_E_RES || epi == PP_E_DACT_GELU;
+    if (akc && !bkc) return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_RES || epi == PP_E_F32;
+    if (!akc && !bkc) return epi == PP_E_F32;
+    return false;
+}
+
+bool md_gemm_pp_eligible(const md_gemm_args* a) {
+    const int epi = pp_epi_kind(a);
+    if (epi < 0 || !pp_instantiated(a->a_kcontig, a->b_kcontig, epi)) return false;
+    if (a->K % a->ksplit) return false;
+    const int64_t kspan = a->K / a->ksplit;
+    if (kspan < 128 || kspan % 128) return false;
+    if (a->N % 8) return false;                                  // 16-byte column chunks everywhere
+    if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
+    if (a->M >= (1 << 30) || a->N >= (1 << 30) || a->K >= (1 << 30)) return false;
+    if (a->lda > (1 << 22) || a->ldb > (1 << 22)) return false;  // 32-bit per-lane DMA offsets
+    return true;
+}
+
+int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
+    PPPlan w;
+    w.ntm = (int)((a->M + PT - 1) / PT);
+    w.ntn = (int)((a->N + PT - 1) / PT);
+    w.ntiles = w.ntm * w.ntn;
+    const int64_t total = (int64_t)w.ntiles * a->batch * a->ksplit;
+    if (total > (1 << 30)) return MD_BAD_ARG;
+    w.total = (int)total;
+    w.kspan = (int)(a->K / a->ksplit);
+    w.nk = w.kspan / BKT;
+    w.group_n = a->raster_group_n > 0 ? a->raster_group_n : 1;
+    w.M = (int)a->M; w.N = (int)a->N; w.ksplit = a->ksplit;
+    w.lda = (int)a->lda; w.ldb = (int)a->ldb;
+    const unsigned G = (unsigned)(total < NUM_CU ? total : NUM_CU);
+    const dim3 grid(G, 1, 1), block(512);
+    const int epi = pp_epi_kind(a);
+#define PP_LAUNCH(AK, BK, E) hipLaunchKernelGGL((gemm_bf16_pp_kernel<AK, BK, E>), grid, block, 0, stream, *a, w)
+#ifdef PP_EXPERIMENT_ONE   // compile-time experiments: a single instantiation
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<PP_EXPERIMENT_ONE>), grid, block, 0, stream, *a, w);
+    (void)epi;
+#else
+    if (a->a_kcontig && a->b_kcontig) {
+        if (epi == PP_E_BF16) PP_LAUNCH(1, 1, PP_E_BF16);
+        else if (epi == PP_E_RES) PP_LAUNCH(1, 1, PP_E_RES);
+        else PP_LAUNCH(1, 1, PP_E_DACT_GELU);
+    } else if (a->a_kcontig) {
+        if (epi == PP_E_BF16) PP_LAUNCH(1, 0, PP_E_BF16);
+        else if (epi == PP_E_BF16_GELU) PP_LAUNCH(1, 0, PP_E_BF16_GELU);
+        else if (epi == PP_E_RES) PP_LAUNCH(1, 0, PP_E_RES);
+        else PP_LAUNCH(1, 0, PP_E_F32);
+    } else {
+        PP_LAUNCH(0, 0, PP_E_F32);
+    }
+#endif
+#undef PP_LAUNCH
+    MD_LAUNCH_CHECK();
+    return 0;
+}

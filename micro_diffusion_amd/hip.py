@@ -25,6 +25,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-
 # enums (mirror include/microdit_hip.h)
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
 EPI_STORE_BF16, EPI_RESIDUAL, EPI_STORE_F32, EPI_ACCUM_F32, EPI_ATOMIC_F32, EPI_DACT = 0, 1, 2, 3, 4, 5
+GEMM_AUTO, GEMM_REG128, GEMM_DMA128, GEMM_PACED256, GEMM_PP256 = 0, 1, 2, 3, 4
+GEMM_VARIANT_NAMES = {"auto": 0, "reg128": 1, "dma128": 2, "paced256": 3, "pp256": 4}
 
 
 def _sources():
@@ -88,7 +90,8 @@ class GemmArgs(Structure):
         ("sAux", c_int64), ("sSplit", c_int64),
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
-        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("reserved0", c_int32), ("raster_group_n", c_int32),
+        ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
+        ("timeline", c_void_p),
     ]
 
 
@@ -116,7 +119,7 @@ def lib() -> ctypes.CDLL:
                 "There is no CPU / PyTorch fallback for the training path.")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.md_abi_version() != 1:
+        if _lib.md_abi_version() != 2:
             raise RuntimeError("libmicrodit_hip.so ABI version mismatch; rebuild")
     return _lib
 
@@ -204,7 +207,6 @@ _sig("md_sumsq", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_debug_tr_probe", P, P, P)
 _sig("md_debug_mfma_probe", P, P, P, P)
-_sig("md_debug_gemm_timeline", P)
 
 
 def _declare(l: ctypes.CDLL) -> None:
@@ -229,7 +231,7 @@ def stream_ptr():
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
-         stream=None):
+         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
     def ptr(x):
         if x is None:
@@ -237,5 +239,9 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
         return x if isinstance(x, int) else x.data_ptr()
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
-                 rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha)
-    check(lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr()), "md_gemm_bf16")
+                 rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
+                 ptr(timeline))
+    rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())
+    if expect is None:
+        return rc
+    check(rc, "md_gemm_bf16")
