@@ -51,6 +51,8 @@ class DiTEngine:
         self.L = hip.lib()
         self.wgrad_target_blocks = 768
         self.gemm_profile = None
+        self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
+        self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
         self.ws = torch.empty(128 << 20, device=self.dev, dtype=F32)  # 512 MiB split-K workspace
 
     # ------------------------------------------------------------------------------------------ launch helpers
@@ -71,7 +73,17 @@ class DiTEngine:
         if prof is not None:      # per-launch HIP events on the launch stream (bench.py roofline leg)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(self.L.md_gemm_bf16(byref(a), self._st()), "md_gemm_bf16")
+        rc = -1
+        if self.gemm_prefer != hip.GEMM_AUTO:
+            a.variant = self.gemm_prefer
+            rc = self.L.md_gemm_bf16(byref(a), self._st())      # -1: the forced kernel refuses this problem (nothing was launched)
+            if rc == -1:
+                a.variant = hip.GEMM_AUTO
+        if rc == -1:
+            rc = self.L.md_gemm_bf16(byref(a), self._st())
+        hip.check(rc, "md_gemm_bf16")
+        if self.gemm_log is not None:
+            self.gemm_log.append((a.variant, a.M, a.N, a.K, a.batch))
         if prof is not None:
             e1.record()
             prof.append((e0, e1, 2.0 * a.M * a.N * a.K * a.batch, (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit)))
@@ -105,21 +117,26 @@ class DiTEngine:
     def _ksplit(self, out_rows, out_cols, contraction, batch=1):
         """Split-K factor for GEMMs whose output is too small to fill the chip (weight gradients, skinny dgrads).
 
-        Long contractions run on the 256 x 256 single-workgroup-per-CU kernel, which is at its best (830-1020 TFLOP/s,
-        profiles/r1_wgrad_splitk.txt) when tiles x splits make whole rounds of 256 workgroups: pick the factor that
-        minimises  rounds x (K / ks + ~1024 k of un-overlapped prologue + fp32 epilogue)  + the slice reduction's
-        traffic.  Short contractions keep the 128 x 128 rule (~3 workgroups per CU, >= 512 k per split)."""
+        Preferred: a factor the persistent 256 x 256 kernel (pp256) accepts — the contraction per split a multiple of 128 —
+        chosen by a small cost model of that kernel (profiles/r2_wgrad_splitk_pp256.txt): the tiles x splits work items
+        are dealt out to the 256 CUs, a workgroup needs ~1.9 us per 64-deep k-tile plus ~5 us to write a 256 x 256 fp32
+        slice, and the slice reduction moves (ks + 2) x the output once at ~4 TB/s.  Otherwise (ragged contraction,
+        tiny outputs) the round-1 rule for the 2-stage kernels: ~3 workgroups of 128 x 128 per CU, >= 512 k per split."""
         ws_cap = max(1, self.ws.numel() // (out_rows * out_cols * batch))
         t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256) * batch
-        out_mb = out_rows * out_cols * batch * 4 / 4e6              # microseconds to move the output once at ~4 TB/s
-        best, best_cost = 1, None
-        for ks in range(1, min(64, ws_cap, max(1, contraction // 1024)) + 1):
-            rounds = -(-t256 * ks // 256)
-            cost = rounds * (contraction / ks + 1024) * 0.0335 + (2 if ks == 1 else ks + 2) * out_mb
-            if best_cost is None or cost < best_cost:
-                best, best_cost = ks, cost
-        if contraction // best >= 1024 and t256 * best >= 128:
-            return best
+        if contraction % 128 == 0 and out_cols % 8 == 0:
+            units = contraction // 128
+            out_us = out_rows * out_cols * batch * 4 / 4e6
+            best, best_cost = None, None
+            for ks in range(2, min(64, ws_cap, units) + 1):
+                if units % ks or t256 * ks < 128:
+                    continue
+                per_wg = -(-t256 * ks // 256)
+                cost = per_wg * (contraction / ks / 64 * 1.9 + 5.0) + (ks + 2) * out_us
+                if best_cost is None or cost < best_cost:
+                    best, best_cost = ks, cost
+            if best is not None:
+                return best
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * batch
         ks = max(1, self.wgrad_target_blocks // tiles)
         ks = min(ks, max(1, contraction // 512))

@@ -138,6 +138,8 @@ def gen_model(tag, cfg, B, seed, mask_ratio, p_mean, p_std, cap_len):
     keep = ["final_layer.linear.weight", "x_embedder.proj.weight", "t_embedder.mlp.0.bias",
             "blocks.0.adaLN_modulation.1.bias", "patch_mixer.1.mlp.gate.weight", "blocks.1.norm3.weight",
             "y_emb_preprocess.norm1.weight", "patch_mixer.0.attn.qkv.weight"]
+    if cfg.dim >= 1024:     # XL/2: keep the fixture small (the 478 gradient norms / sums pin every tensor)
+        keep = keep[:7] + ["blocks.25.mlp.gate.weight", "blocks.27.norm3.weight"]
     for k in keep:
         if k in grads:
             out["grad::" + k] = grads[k].numpy()
@@ -215,6 +217,10 @@ def gen_sampler():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "res512":
         gen_model("tiny512_mask75", orc.tiny512_config(), 2, 14, 0.75, 0.0, 0.6, 77)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2":
+        # BASELINE.json configs[1] geometry (MicroDiT_XL_2, dit.py:671-709), batch 2: ~25 GB of host memory, ~1 min
+        gen_model("xl2_mask75", orc.xl2_config(), 2, 41, 0.75, -0.6, 1.2, 77)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sampler":
         gen_sampler()

@@ -1,6 +1,6 @@
 """Weight-gradient GEMMs (TN layout: both operands K-strided, fp32 split-K slices + reduce) of one XL/2 microbatch of
-1024 images: TFLOP/s per (shape, split-K factor) for the GEMM variant selected with MD_GEMM_VARIANT (unset = the
-library's own choice).  Usage: [MD_GEMM_VARIANT=paced256] python scripts/bench_wgrad.py [--iters 5]"""
+1024 images: TFLOP/s per (shape, split-K factor) for one GEMM kernel (--variant; default = the library's own choice).
+Usage: python scripts/bench_wgrad.py [--variant paced256|pp256|...] [--iters 5]"""
 import argparse
 import os
 import sys
@@ -21,10 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mb", type=int, default=1024, help="microbatch the contraction lengths are scaled to (1024 = table as is)")
+    ap.add_argument("--variant", default="auto")
     a = ap.parse_args()
+    var = hip.GEMM_VARIANT_NAMES[a.variant]
     L = hip.lib()
     ws = torch.empty(64 << 20, device="cuda")       # 256 MiB of fp32 slices
-    print(f"# MD_GEMM_VARIANT={os.environ.get('MD_GEMM_VARIANT', '(auto)')}")
+    print(f"# variant {a.variant}")
     for (M, N, K, batch, cnt) in SHAPES:
         K = K * a.mb // 1024
         A = torch.randn(batch, K, M, device="cuda").bfloat16()
@@ -32,7 +34,7 @@ def main():
         out = torch.zeros(batch, M, N, device="cuda")
         t128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
         t256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
-        cands = sorted({max(1, 768 // t128), max(1, 256 // t256), max(1, 512 // t256), max(1, 768 // t256)})
+        cands = sorted({max(1, 768 // t128), max(1, 256 // t256), max(1, 512 // t256), max(1, 768 // t256)} | {k for k in (2, 4, 8, 16, 32) if 128 <= k * t256 <= 1024})
         row = []
         for ks in cands:
             if ks * M * N * batch > ws.numel():
@@ -40,12 +42,15 @@ def main():
             def run():
                 if ks == 1:
                     hip.gemm(A, B, out, M, N, K, lda=M, ldb=N, ldc=N, a_kcontig=0, b_kcontig=0, mode=hip.EPI_ACCUM_F32,
-                             batch=batch, sA=K * M, sB=K * N, sC=M * N)
+                             batch=batch, sA=K * M, sB=K * N, sC=M * N, variant=var)
                 else:
                     hip.gemm(A, B, ws, M, N, K, lda=M, ldb=N, ldc=N, a_kcontig=0, b_kcontig=0, mode=hip.EPI_STORE_F32,
-                             batch=batch, sA=K * M, sB=K * N, sC=ks * M * N, sSplit=M * N, ksplit=ks)
+                             batch=batch, sA=K * M, sB=K * N, sC=ks * M * N, sSplit=M * N, ksplit=ks, variant=var)
                     hip.check(L.md_splitk_reduce(ws.data_ptr(), out.data_ptr(), M, N, N, M * N, ks, batch, 1, hip.stream_ptr()), "reduce")
-            run()
+            try:
+                run()
+            except RuntimeError:      # the forced kernel refuses this problem
+                continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -1,6 +1,6 @@
-"""Where does a GEMM launch spend its time?  Per-workgroup shader-clock stamps (md_debug_gemm_timeline) of one shape:
+"""Where does a GEMM launch spend its time?  Per-workgroup shader-clock stamps (md_gemm_args.timeline) of one shape:
 prologue (entry -> first tile landed), k-loop, epilogue (incl. store drain), and the gap between consecutive workgroups
-on the same CU slot.  Usage: [MD_GEMM_VARIANT=...] python scripts/gemm_timeline.py M N K akc bkc [mode: bf16|res|f32]"""
+on the same CU slot.  Usage: python scripts/gemm_timeline.py M N K akc bkc [mode: bf16|res|f32] [variant: auto|reg128|dma128|paced256]"""
 import os
 import sys
 
@@ -11,21 +11,22 @@ from micro_diffusion_amd import hip   # noqa: E402
 
 M, N, K, akc, bkc = [int(v) for v in sys.argv[1:6]]
 mode = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+variant = sys.argv[7] if len(sys.argv) > 7 else "auto"
 dev = "cuda"
 A = torch.randn((M, K) if akc else (K, M), device=dev).bfloat16()
 B = torch.randn((N, K) if bkc else (K, N), device=dev).bfloat16()
 C = torch.zeros(M, N, device=dev, dtype=torch.float32 if mode == "f32" else torch.bfloat16)
 res = torch.randn(M, N, device=dev).bfloat16() if mode == "res" else None
 gate = torch.randn(M // 64, N, device=dev).bfloat16() if mode == "res" else None
-kw = dict(lda=K if akc else M, ldb=K if bkc else N, ldc=N, a_kcontig=akc, b_kcontig=bkc)
+kw = dict(lda=K if akc else M, ldb=K if bkc else N, ldc=N, a_kcontig=akc, b_kcontig=bkc, variant=hip.GEMM_VARIANT_NAMES[variant])
 if mode == "res":
     kw.update(mode=hip.EPI_RESIDUAL, res=res, ldr=N, gate=gate, ldg=N, rows_per_sample=64)
 elif mode == "f32":
     kw.update(mode=hip.EPI_STORE_F32)
 
 
-def run():
-    hip.gemm(A, B, C, M, N, K, **kw)
+def run(timeline=None):
+    hip.gemm(A, B, C, M, N, K, timeline=timeline, **kw)
 
 
 for _ in range(3):
@@ -38,18 +39,15 @@ for _ in range(5):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"shape {M}x{N}x{K} layout {akc}{bkc} epilogue {mode} variant {os.environ.get('MD_GEMM_VARIANT', 'auto')}: "
+print(f"shape {M}x{N}x{K} layout {akc}{bkc} epilogue {mode} variant {variant}: "
       f"{ms * 1e3:.1f} us, {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s (un-instrumented)")
 
 nblk_max = ((M + 127) // 128) * ((N + 127) // 128)
 tl = torch.zeros(nblk_max * 8, dtype=torch.int64, device=dev)
-L = hip.lib()
-hip.check(L.md_debug_gemm_timeline(tl.data_ptr()), "timeline on")
 e0.record()
-run()
+run(tl)
 e1.record()
 torch.cuda.synchronize()
-hip.check(L.md_debug_gemm_timeline(None), "timeline off")
 t = tl.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] != 0]
 n = len(t)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.md_abi_version() == 1
+    assert lib.md_abi_version() == 2
 
 
 def test_product_never_imports_oracle():
@@ -105,9 +105,10 @@ def test_grad_buckets_cover_flat_buffer_once_gloo_ws2():
 
 
 def test_splitk_factor_fills_whole_rounds():
-    """DiTEngine._ksplit (host logic, no GPU): weight-gradient GEMMs are split so that 256x256 tiles x splits make whole
-    rounds of the 256 CUs — the factors measured best on MI355X (profiles/r1_wgrad_splitk.txt) — and never exceed the
-    workspace; short contractions keep at least 512 elements per split."""
+    """DiTEngine._ksplit (host logic, no GPU): weight-gradient GEMMs get a split-K factor the persistent 256 x 256 kernel
+    accepts (contraction per split a multiple of 128) that deals at least half a round of work items to the 256 CUs and
+    fits the workspace; the two heaviest XL/2 weight-gradient shapes keep the factors measured best on MI355X
+    (profiles/r2_gemm_variants_mb1024_call1.txt); ragged contractions fall back to the 128 x 128 rule (>= 512 k per split)."""
     import types
     from micro_diffusion_amd.engine import DiTEngine
 
@@ -116,15 +117,15 @@ def test_splitk_factor_fills_whole_rounds():
             return 128 << 20
     eng = types.SimpleNamespace(ws=_WS(), wgrad_target_blocks=768)
     pick = lambda *a: DiTEngine._ksplit(eng, *a)   # noqa: E731
-    # (out_rows, out_cols, contraction, batch) -> measured-best factor at microbatch 1024 ...
-    assert pick(1024, 1024, 65536, 1) == 16        # 16 tiles x 16 = 256 workgroups
-    assert pick(2048, 1024, 78848, 1) == 8
-    assert pick(768, 768, 262144, 1) == 28         # 9 tiles x 28 = 252
-    assert pick(5376, 1024, 65536, 1) == 3         # 84 tiles x 3 = 252
-    # ... and at microbatch 256 (the per-rank shape of an 8-GPU run)
-    assert pick(1024, 1024, 16384, 1) == 16
-    assert pick(3072, 1024, 16384, 1) == 5
-    for shape in [(1024, 1024, 65536, 1), (768, 3072, 65536, 8), (16, 1024, 65536, 1), (256, 256, 1024, 1), (1024, 8, 512, 1)]:
+    assert pick(1024, 1024, 65536, 1) == 16        # 16 tiles x 16 = 256 work items, one per CU
+    assert pick(2048, 1024, 78848, 1) == 8         # 32 tiles x 8 = 256
+    assert pick(1024, 1024, 16384, 1) == 16        # microbatch 256 (the per-rank shape of an 8-GPU run)
+    assert pick(78848, 1024, 2048, 1) == 1         # output larger than the workspace: accumulate in place
+    for shape in [(1024, 1024, 65536, 1), (768, 3072, 65536, 8), (16, 1024, 65536, 1), (256, 256, 1024, 1), (1024, 8, 512, 1),
+                  (768, 768, 262144, 1), (5376, 1024, 65536, 1), (3072, 1024, 16384, 1), (6144, 1024, 1024, 1), (1024, 1024, 1000, 1)]:
         ks = pick(*shape)
-        assert 1 <= ks <= 64 and ks * shape[0] * shape[1] * shape[3] <= (128 << 20)
-        assert shape[2] // ks >= 512 or ks == 1
+        rows, cols, K, batch = shape
+        assert 1 <= ks <= 64 and ks * rows * cols * batch <= (128 << 20)
+        t256 = ((rows + 255) // 256) * ((cols + 255) // 256) * batch
+        pp256_pick = ks > 1 and K % (128 * ks) == 0 and t256 * ks >= 128
+        assert pp256_pick or K // ks >= 512 or ks == 1

@@ -442,3 +442,57 @@ def test_adamw_clip(hip):
         assert torch.allclose(p, pref.detach(), rtol=1e-5, atol=1e-6), (p - pref.detach()).abs().max()
         assert gw.abs().max() == 0
         assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------ MoE layer, routing injected
+@pytest.mark.parametrize("variant", ["auto", "pp256"])
+@pytest.mark.parametrize("B,S,d,f", [(16, 64, 1024, 3840), (4, 256, 768, 3072)])
+def test_moe_layer_with_oracle_routing(hip, variant, B, S, d, f):
+    """SURVEY.md section 8c golden (ii): the expert-choice MoE layer (dit.py:126-143) at XL/2 geometry (backbone block 25:
+    dim 1024, hidden 3840, 64 kept tokens; mixer: dim 768, hidden 3072, 256 tokens; 8 experts, capacity 2) with the
+    ORACLE's top-k indices injected, so routing flips cannot hide (or be blamed for) arithmetic error: gather -> grouped
+    fc1 (GELU-erf) -> grouped fc2 -> gate-weighted combine through the HIP kernels vs oracle.ec_moe in fp32 on the same
+    bf16-rounded weights and inputs.  With identical routing the only difference is bf16 storage of xin / h / h2."""
+    from oracle import microdit_ref as orc
+    torch.manual_seed(B + S)
+    L, st = hip.lib(), hip.stream_ptr()
+    E, k = 8, int(2.0 * S / 8)
+    M, Bk = B * S, B * k
+    x = bf(torch.randn(B, S, d))
+    sd = {"m.gate.weight": torch.randn(E, d) * (2.0 / math.sqrt(d)), "m.w1": bf(torch.randn(E, d, f) / math.sqrt(d)).float(),
+          "m.w2": bf(torch.randn(E, f, d) / math.sqrt(f)).float()}
+    ref, m_idx, g = orc.ec_moe(sd, "m", x.float(), E, 2.0, return_routing=True)          # [B,S,d], [B,E,k], [B,E,k]
+    # ---- routing tables in the HIP kernels' layout, from the oracle's indices
+    rowidx = (m_idx + (torch.arange(B) * S).view(B, 1, 1)).permute(1, 0, 2).reshape(E, Bk).to(torch.int32).to(DEV)
+    gval = g.permute(1, 0, 2).reshape(E, Bk).contiguous().to(DEV)
+    slot = torch.full((B, S, E), -1, dtype=torch.int32)
+    for e in range(E):
+        slot[:, :, e].scatter_(1, m_idx[:, e, :], torch.arange(k, dtype=torch.int32).view(1, k).expand(B, k))
+    slot = slot.view(M, E).to(DEV)
+    xg = x.view(M, d).to(DEV)
+    xin = torch.empty(E, Bk, d, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_gather_rows(xg.data_ptr(), d, rowidx.data_ptr(), xin.data_ptr(), d, E * Bk, d, st), "gather")
+    w1, w2 = bf(sd["m.w1"]).to(DEV), bf(sd["m.w2"]).to(DEV)
+    hact = torch.empty(E, Bk, f, device=DEV, dtype=torch.bfloat16)
+    hpre = torch.empty_like(hact)
+    v = hip.GEMM_VARIANT_NAMES[variant]
+
+    def gemm(**kw):
+        rc = hip.gemm(variant=v, expect=None, **kw)
+        if rc == -1:
+            rc = hip.gemm(variant=hip.GEMM_AUTO, expect=None, **kw)
+        hip.check(rc, "gemm")
+    gemm(A=xin, B=w1, C=hact, C2=hpre, M=Bk, N=f, K=d, lda=d, ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f, sC2=Bk * f,
+         batch=E, a_kcontig=1, b_kcontig=0, act=hip.ACT_GELU_ERF)
+    h2 = torch.empty(E, Bk, d, device=DEV, dtype=torch.bfloat16)
+    gemm(A=hact, B=w2, C=h2, M=Bk, N=d, K=f, lda=f, ldb=d, ldc=d, sA=Bk * f, sB=f * d, sC=Bk * d, batch=E, a_kcontig=1, b_kcontig=0)
+    res = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    gate = torch.ones(B, 6 * d, device=DEV, dtype=torch.bfloat16)
+    br = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    out = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_moe_combine(h2.data_ptr(), gval.data_ptr(), slot.data_ptr(), res.data_ptr(), gate[:, 5 * d:].data_ptr(), 6 * d,
+                               br.data_ptr(), out.data_ptr(), B, S, E, k, d, st), "combine")
+    torch.cuda.synchronize()
+    rr = rel_rms(br.cpu().view(B, S, d), ref)
+    assert rr <= 0.01, f"MoE layer with injected routing: rel-RMS {rr:.4f} vs fp32 oracle (bf16 storage only: expected ~0.004)"
+    close(out, br, rel=1e-2, what="res 0 + gate 1")

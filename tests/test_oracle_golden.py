@@ -120,3 +120,24 @@ def test_sampler_matches_reference(tag, guidance):
     ref = torch.from_numpy(g[tag])
     assert x.shape == ref.shape
     assert (x - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_xl2_forward_matches_reference():
+    """BASELINE.json configs[1] geometry (MicroDiT_XL_2, dit.py:671-709: head_dim 64, per-layer head counts 8..16, FFN hidden
+    512..3840, 8 experts): loss, raw network output and mask of the oracle vs the reference's own run (tests/golden/xl2_mask75.npz,
+    oracle/gen_golden.py xl2).  Forward only — the 478 gradient norms of the same fixture are checked on the GPU box by
+    tests/test_engine_gpu.py::test_xl2_train_step_parity through the oracle's backward."""
+    z = np.load(os.path.join(G, "xl2_mask75.npz"))
+    cfg = orc.xl2_config()
+    sd = orc.synth_state_dict(cfg, 41)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 2, 42)
+    with torch.no_grad():
+        loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, 0.75, -0.6, 1.2)
+        assert abs(loss.item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
+        sigma = (rnd * 1.2 - 0.6).exp()
+        xin = (batch["image_latents"].float() + epsn * sigma) / (0.9 ** 2 + sigma ** 2).sqrt()
+        cond = batch["caption_latents"].float() * batch["drop_caption_mask"].view(-1, 1, 1, 1)
+        sample, mask = orc.dit_forward(sd, cfg, xin, (sigma.log() / 4).flatten(), cond, 0.75, mnoise)
+    assert np.abs(sample.numpy() - z["sample"]).max() <= 1e-4 * np.abs(z["sample"]).max()
+    assert np.array_equal(mask.numpy(), z["mask"])
+    assert len(z["grad_keys"]) == 476          # 478 state_dict entries minus the two buffers
