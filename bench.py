@@ -1,11 +1,22 @@
 """Headline benchmark: training images/sec of MicroDiT-XL/2 (res_256_pretrain: 32x32x4 latents, mask 0.75, bf16,
 global batch 2048) on N MI355X GPUs — one full optimisation step per "step": all microbatches fwd+bwd, gradient
-all-reduce (N > 1), clip, AdamW.  Prints ONE JSON line (contract in the task description).
+exchange (N > 1), clip, AdamW.  Prints ONE JSON line (contract in the task description).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Extra keys of the line (the headline fields are unchanged by them):
+  other_stages   the same full step on the reference's other stage configs (BASELINE.json configs[3], [4]):
+                 res_256_finetune (mask 0: 256 backbone tokens) and res_512_pretrain (64x64 latents, pos_interp_scale 2),
+                 1 warm-up + 2 timed steps each, N = 1 only (--no-other-stages skips them);
+  value_mb256    the headline step with the YAML microbatch (256 = the per-rank shape of an 8-GPU run), N = 1 only;
+  roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
+                 the committed rocprofv3 PMC pass (profiles/r2_gemm_traffic.json; null when that file is absent);
+  cpu_baseline   the CPU restatement of the reference step on the host cores (kind "port": the reference is pure Python and
+                 /root/reference does not travel to the GPU box), >= 3 timed steps, threads used and host cores stated.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -19,6 +30,17 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_BWD_GFLOP_PER_IMG = {("res256", 0.75): 282.3, ("res256", 0.0): 714.4, ("res512", 0.75): 1069.4, ("res512", 0.0): 3002.8}
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md (dense; AMD's 5 PF figure is 2:1 sparse)
+# The reference's training stages (configs/*.yaml; BASELINE.json configs[1], [3], [4]).  `microbatch` is this repo's
+# HBM-sized default per stage (the YAML values 256 / 64 / 32 are 80 GB-H100 settings; any split accumulates the same gradient).
+STAGES = {
+    "res_256_pretrain": dict(latent_res=32, pos_interp_scale=1.0, mask=0.75, p_mean=-0.6, p_std=1.2, lr=2.4e-4, clip=0.25,
+                             microbatch=1024, key=("res256", 0.75),
+                             sched=("cosine_with_warmup", dict(t_warmup="2500ba", t_max="250000ba", alpha_f=0.33))),
+    "res_256_finetune": dict(latent_res=32, pos_interp_scale=1.0, mask=0.0, p_mean=-0.6, p_std=1.2, lr=8e-5, clip=0.25,
+                             microbatch=256, key=("res256", 0.0), sched=("constant", dict(alpha=1.0))),
+    "res_512_pretrain": dict(latent_res=64, pos_interp_scale=2.0, mask=0.75, p_mean=0.0, p_std=0.6, lr=8e-5, clip=0.5,
+                             microbatch=256, key=("res512", 0.75), sched=("constant_with_warmup", dict(t_warmup="500ba", alpha=1.0))),
+}
 
 
 def dezero_(dit, seed=1234):
@@ -33,17 +55,17 @@ def dezero_(dit, seed=1234):
 
 
 CPU_BASELINE_THREADS_CAP = 32      # torch CPU ops with hundreds of threads on small tensors oversubscribe badly
-CPU_BASELINE_TIMEOUT_S = 240
+CPU_BASELINE_TIMEOUT_S = 300
+CPU_BASELINE_STEPS = 3             # timed steps after one warm-up
 
 
 def _cpu_baseline_worker():
     """Runs in a child process: the oracle (CPU restatement of the reference step: fwd + bwd + clip + AdamW) on the host
-    cores, MicroDiT-XL/2, batch 4, 1 warm-up + 1..2 timed steps.  Prints one JSON object."""
+    cores, MicroDiT-XL/2, batch 4, 1 warm-up + CPU_BASELINE_STEPS timed steps.  Prints one JSON object."""
     from oracle import microdit_ref as orc
     threads = max(1, min(os.cpu_count() or 1, CPU_BASELINE_THREADS_CAP))
     torch.set_num_threads(threads)
     cfg = orc.xl2_config()
-    t0 = time.time()
     sd = orc.synth_state_dict(cfg, 3)
     names = [k for k in sd if k not in ("pos_embed", "mask_token")]
     for k in names:
@@ -53,26 +75,24 @@ def _cpu_baseline_worker():
     B = 4
     batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, 4)
     times = []
-    step = 0
-    while True:
+    for step in range(1, CPU_BASELINE_STEPS + 2):
         ts = time.time()
         loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, 0.75, -0.6, 1.2)
         loss.backward()
         with torch.no_grad():
             grads = [sd[k].grad for k in names]
             orc.clip_grad_norm(grads, 0.25)
-            step += 1
             for k in names:
                 orc.adamw_step(sd[k], sd[k].grad, m[k], v[k], step, 2.4e-4)
                 sd[k].grad = None
         times.append(time.time() - ts)
-        if step >= 3 or (step >= 2 and time.time() - t0 > 60.0):
-            break
     per = sum(times[1:]) / len(times[1:])          # first step = warm-up
-    print(json.dumps({"value": B / per, "unit": "images/sec", "cores": threads, "kind": "port",
-                      "sample": f"oracle (CPU fp32 restatement of the reference step: fwd+bwd+clip+AdamW) MicroDiT-XL/2 "
-                                f"mask=0.75, batch {B}, {len(times) - 1} timed step(s) after 1 warm-up, {per:.2f} s/step, "
-                                f"{threads} threads of {os.cpu_count()} host cores"}), flush=True)
+    print(json.dumps({"value": B / per, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+                      "sample": f"oracle/microdit_ref.py (CPU fp32 restatement of the reference step: LatentDiffusion.forward + backward + "
+                                f"clip_grad_norm_ + AdamW, pinned to the reference by tests/golden/xl2_mask75.npz) MicroDiT-XL/2 mask=0.75, "
+                                f"batch {B}, {len(times) - 1} timed steps after 1 warm-up, {per:.2f} s/step, torch.set_num_threads({threads}) "
+                                f"on a {os.cpu_count()}-core host; the reference itself is Python under /root/reference, which does not "
+                                f"exist on the GPU box"}), flush=True)
 
 
 def cpu_baseline():
@@ -86,8 +106,83 @@ def cpu_baseline():
                 return json.loads(line)
         raise RuntimeError((r.stderr or r.stdout)[-300:])
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "images/sec", "cores": min(os.cpu_count() or 1, CPU_BASELINE_THREADS_CAP), "kind": "port",
-                "sample": f"oracle XL/2 batch 4 did not finish 2 steps within {CPU_BASELINE_TIMEOUT_S} s on this host"}
+        return {"value": None, "unit": "images/sec", "cores": min(os.cpu_count() or 1, CPU_BASELINE_THREADS_CAP),
+                "host_cores": os.cpu_count(), "kind": "port",
+                "sample": f"oracle XL/2 batch 4 did not finish {CPU_BASELINE_STEPS + 1} steps within {CPU_BASELINE_TIMEOUT_S} s on this host"}
+
+
+class Stage:
+    """Model + optimiser + synthetic rank batch of one training stage; `step()` = one full optimisation step."""
+
+    def __init__(self, name, arch, global_batch, microbatch, world, rank):
+        from micro_diffusion_amd.model import create_latent_diffusion
+        from micro_diffusion_amd.trainer import FusedAdamW, LRSchedule, Trainer
+        st = STAGES[name]
+        self.name, self.st = name, st
+        torch.manual_seed(18)                       # configs/*.yaml: seed 18 (same init on every rank)
+        self.model = create_latent_diffusion(dit_arch=arch, latent_res=st["latent_res"], in_channels=4, pos_interp_scale=st["pos_interp_scale"],
+                                             dtype="bfloat16", precomputed_latents=True, p_mean=st["p_mean"], p_std=st["p_std"],
+                                             train_mask_ratio=st["mask"])
+        self.model.dit.to("cuda")
+        dezero_(self.model.dit)
+        self.model.train()
+        opt = FusedAdamW(self.model.dit, lr=st["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+        kind, kw = st["sched"]
+        self.trainer = Trainer(self.model, opt, LRSchedule(kind, **kw), clip_norm=st["clip"], microbatch_size=microbatch)
+        self.trainer.batches_seen = 100          # a non-zero LR (the warm-up schedules' first batch runs at lr = 0)
+        per_rank = global_batch // world
+        self.per_rank, self.microbatch = per_rank, min(microbatch, per_rank)
+        torch.manual_seed(2024 + rank)           # data / noise stream differs per rank (Composer seeds rank-wise)
+        g = torch.Generator(device="cuda").manual_seed(2024 + rank)
+        r = st["latent_res"]
+        self.batch = {
+            "image_latents": (torch.randn(per_rank, 4, r, r, device="cuda", generator=g) * 0.8).half(),
+            "caption_latents": torch.randn(per_rank, 1, 77, 1024, device="cuda", generator=g).half(),
+            "drop_caption_mask": (torch.rand(per_rank, device="cuda", generator=g) >= 0.1).float(),
+        }
+        self.caps = self.batch["caption_latents"].clone()
+
+    def step(self):
+        self.batch["caption_latents"].copy_(self.caps)   # forward() zeroes dropped captions in place, like the reference
+        return self.trainer.train_step(self.batch)
+
+    def timed(self, steps, warmup, world):
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(steps):
+            loss = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, float(loss.item())
+
+    def close(self):
+        self.model = self.trainer = self.batch = self.caps = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def gemm_traffic():
+    """HBM bytes per GEMM launch of the headline step from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 and
+    WRITE_SIZE in separate --pmc runs of this command; scripts/pmc_traffic.py writes the file)."""
+    path = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    return t.get("bytes_per_launch"), t
 
 
 def main():
@@ -99,10 +194,11 @@ def main():
     ap.add_argument("--microbatch", type=int, default=1024,
                     help="gradient-accumulation microbatch per rank.  res_256_pretrain.yaml says 256, which is an 80 GB-H100 "
                          "memory setting (Composer also accepts 'auto'); the accumulated gradient of the rank batch is the same "
-                         "for any split, and 288 GB of HBM3E holds 1024 (205 GB peak at N=1), which is 12 %% faster than 256")
+                         "for any split, and 288 GB of HBM3E holds 1024 (205 GB peak at N=1)")
     ap.add_argument("--arch", default="MicroDiT_XL_2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-other-stages", action="store_true", help="skip the res_256_finetune / res_512_pretrain / microbatch-256 legs")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -124,56 +220,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from micro_diffusion_amd.model import create_latent_diffusion
-    from micro_diffusion_amd.trainer import FusedAdamW, LRSchedule, Trainer
-
-    torch.manual_seed(18)                       # configs/res_256_pretrain.yaml: seed 18 (same init on every rank)
-    model = create_latent_diffusion(dit_arch=args.arch, latent_res=32, in_channels=4, pos_interp_scale=1.0,
-                                    dtype="bfloat16", precomputed_latents=True, p_mean=-0.6, p_std=1.2, train_mask_ratio=0.75)
-    model.dit.to("cuda")
-    dezero_(model.dit)
-    model.train()
-    opt = FusedAdamW(model.dit, lr=2.4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
-    sched = LRSchedule("cosine_with_warmup", t_warmup="2500ba", t_max="250000ba", alpha_f=0.33)
-    trainer = Trainer(model, opt, sched, clip_norm=0.25, microbatch_size=args.microbatch)
-    trainer.batches_seen = 100                   # a non-zero LR (the schedule's first batch runs at lr = 0)
-
-    per_rank = args.global_batch // world
-    torch.manual_seed(2024 + rank)               # data / noise stream differs per rank (Composer seeds rank-wise)
-    g = torch.Generator(device="cuda").manual_seed(2024 + rank)
-    batch = {
-        "image_latents": (torch.randn(per_rank, 4, 32, 32, device="cuda", generator=g) * 0.8).half(),
-        "caption_latents": torch.randn(per_rank, 1, 77, 1024, device="cuda", generator=g).half(),
-        "drop_caption_mask": (torch.rand(per_rank, device="cuda", generator=g) >= 0.1).float(),
-    }
-    caps = batch["caption_latents"].clone()
-
-    def step():
-        batch["caption_latents"].copy_(caps)      # forward() zeroes dropped captions in place, like the reference
-        return trainer.train_step(batch)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss = None
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    head = Stage("res_256_pretrain", args.arch, args.global_batch, args.microbatch, world, rank)
+    elapsed, loss = head.timed(args.steps, args.warmup, world)
     ms_per_step = elapsed / args.steps * 1e3
     value = args.global_batch * args.steps / elapsed
-
+    gf = FWD_BWD_GFLOP_PER_IMG[("res256", 0.75)]
     out = {
         "metric": "training images/sec (global batch 2048) MicroDiT-XL/2 256-res mask=0.75",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,33 +232,55 @@ def main():
         "data": "synthetic (N(0,1)*0.8 fp16 latents 32x32x4, N(0,1) fp16 captions 77x1024, 10% caption drop; "
                 "reference init seed 18 with zero-init tensors perturbed)",
         "config": {"workload": f"{args.arch} res_256_pretrain.yaml mask=0.75, full step = "
-                               f"{per_rank // min(args.microbatch, per_rank)} microbatches x {min(args.microbatch, per_rank)} fwd+bwd"
-                               " + grad all-reduce + clip 0.25 + AdamW",
-                   "global_batch": args.global_batch, "microbatch": min(args.microbatch, per_rank), "parallelism": f"dp{world}"},
-        "loss": float(loss.item()),
-        "step_mfma_frac": value / world * FWD_BWD_GFLOP_PER_IMG[("res256", 0.75)] / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               f"{head.per_rank // head.microbatch} microbatches x {head.microbatch} fwd+bwd"
+                               " + grad exchange + clip 0.25 + AdamW",
+                   "global_batch": args.global_batch, "microbatch": head.microbatch, "parallelism": f"dp{world}",
+                   "grad_exchange": head.trainer.sync.describe() if hasattr(head.trainer.sync, "describe") else None},
+        "loss": loss,
+        "step_mfma_frac": value / world * gf / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS,
     }
 
     if rank == 0 and not args.no_profile:
         # ---- roofline leg: per-launch HIP events around every launch of the dominant kernel (the MFMA GEMM) in one
         # extra, untimed step (events are recorded on the stream the kernels are launched on).
-        eng = model.dit.engine
+        eng = head.model.dit.engine
         eng.gemm_profile = []
         if world == 1:
-            step()
+            head.step()
         else:   # profile a single microbatch locally, without collectives
-            part = {k: v[:args.microbatch] for k, v in batch.items()}
-            model(part)[0].backward()
+            part = {k: v[:head.microbatch] for k, v in head.batch.items()}
+            head.model(part)[0].backward()
         torch.cuda.synchronize()
         prof, eng.gemm_profile = eng.gemm_profile, None
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
         tot_fl = sum(f for _, _, f, _ in prof)
         n = len(prof)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        traffic, tinfo = gemm_traffic()
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_bf16_kernel + gemm_bf16_dma_kernel (md_gemm_bf16 family)",
+                           "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                           "kernel": "md_gemm_bf16 family (gemm_bf16_pp_kernel + gemm_bf16_kernel + gemm_bf16_dma_kernel)",
                            "launches": n, "avg_launch_us": tot_ms * 1e3 / n, "gflop_per_launch": tot_fl / n / 1e9,
-                           "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None}
+                           "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None,
+                           "traffic_source": tinfo}
+    if world == 1 and not args.no_other_stages:
+        # ---- the YAML microbatch (the per-rank shape of an 8-GPU run) on the same model
+        head.trainer.microbatch_size = 256
+        e256, _ = head.timed(2, 1, 1)
+        out["value_mb256"] = args.global_batch * 2 / e256
+        head.trainer.microbatch_size = args.microbatch
+    head.close()
+    if world == 1 and not args.no_other_stages:
+        other = {}
+        for name in ("res_256_finetune", "res_512_pretrain"):
+            st = Stage(name, args.arch, args.global_batch, STAGES[name]["microbatch"], 1, 0)
+            e, l = st.timed(2, 1, 1)
+            v = args.global_batch * 2 / e
+            other[name] = {"value": v, "unit": "images/sec", "ms_per_step": e / 2 * 1e3, "steps": 2, "warmup": 1,
+                           "microbatch": st.microbatch, "loss": l, "gflop_per_image": FWD_BWD_GFLOP_PER_IMG[STAGES[name]["key"]],
+                           "step_mfma_frac": v * FWD_BWD_GFLOP_PER_IMG[STAGES[name]["key"]] / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS}
+            st.close()
+        out["other_stages"] = other
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
                                "sample": "measured at N=1 only (the other ranks would idle behind it)"}

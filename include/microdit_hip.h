@@ -207,15 +207,25 @@ int md_edm_loss(const void* tok, const int32_t* keep_rows, const float* xn, cons
                 int32_t p, float sigma_data, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- optimiser */
-int md_sumsq(const float* g, int64_t n, float* out, hipStream_t stream); /* out += sum g^2 */
-/* clip_grad_norm_ (train.py:85-86) + torch.optim.AdamW (train.py:39-43) + bf16 shadow emit, one pass. */
+/* Sum of squares of a gradient buffer (fp32, or bf16 when g_is_bf16), deterministic: workgroup b of a fixed grid writes
+ * partials[b] (MD_SUMSQ_PARTIALS floats per call); md_sumsq_finish adds `count` partials (several calls' worth, e.g. one per
+ * data-parallel bucket) in a fixed order into out[0].  n must be a multiple of 8. */
+#define MD_SUMSQ_PARTIALS 1024
+int md_sumsq(const void* g, int32_t g_is_bf16, int64_t n, float* partials, hipStream_t stream);
+int md_sumsq_finish(const float* partials, int64_t count, float* out, hipStream_t stream);
+/* clip_grad_norm_ (train.py:85-86) + torch.optim.AdamW (train.py:39-43) + bf16 shadow emit (+ EMA of the weights,
+ * configs/res_512_*.yaml:4-9), one pass. */
 typedef struct md_adamw_args {
-    void *p, *g, *m, *v; /* f32 [n] */
+    void *p, *g, *m, *v; /* f32 [n]; g is zeroed when zero_grad */
     void* shadow;        /* bf16 [n] or NULL */
     const void* sumsq;   /* f32 [1] device: sum of squared (unscaled) grads, or NULL for no clipping */
+    const void* g_bf16;  /* optional bf16 [n]: take the gradient from here (the data-parallel exchange buffer) instead of g */
+    void* ema;           /* optional f32 [n] */
     int64_t n;
     float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm, grad_scale;
+    float ema_smoothing;
     int32_t zero_grad;
+    int32_t ema_mode;    /* 0 = none, 1 = ema <- updated weights (ema_start), 2 = ema <- s * ema + (1 - s) * weights */
 } md_adamw_args;
 int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
 

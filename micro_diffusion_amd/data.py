@@ -166,6 +166,10 @@ class LatentsLoader:
         per_rank = len(dataset) // self.world          # equal share per rank (tail samples rotate in with the shuffle)
         self.samples_per_rank = per_rank
         self.num_batches = per_rank // batch_size if drop_last else -(-per_rank // batch_size)
+        if self.num_batches == 0:
+            # with loop=True the producer would spin forever and the consumer block on an empty queue
+            raise ValueError(f"dataset has {len(dataset)} samples = {per_rank} per rank, fewer than one batch of {batch_size} "
+                             f"on {self.world} rank(s){' (drop_last=True)' if drop_last else ''}")
 
     def __len__(self):
         return self.num_batches
@@ -283,15 +287,22 @@ def build_streaming_latents_dataloader(datadir: Union[str, List[str]], batch_siz
                                        shuffle: bool = True, drop_last: bool = True, **dataloader_kwargs):
     """Same signature as the reference factory (latents_loader.py:73-108).  DataLoader keyword arguments that configure
     worker processes (num_workers, prefetch_factor, persistent_workers, pin_memory) are accepted; `num_workers` sets the
-    number of gather threads and `prefetch_factor` the number of batches in flight."""
-    dirs = [datadir] if isinstance(datadir, str) else list(datadir)
+    number of gather threads and `prefetch_factor` the number of batches in flight.
+
+    A missing / unmounted dataset path raises (like `streaming` does): random latents are served only on explicit request,
+    `datadir="synthetic"` (or `allow_synthetic=True`), which benchmarks and smoke runs use."""
+    allow_synth = bool(dataloader_kwargs.pop("allow_synthetic", False))
+    if isinstance(datadir, str) and datadir == "synthetic":
+        allow_synth, dirs = True, []
+    else:
+        dirs = [datadir] if isinstance(datadir, str) else list(datadir)
     have = [d for d in dirs if os.path.isfile(os.path.join(d, "index.json"))]
-    if not have:
+    if not have and allow_synth:
         rank = int(os.environ.get("RANK", "0"))
         return SyntheticLatents(batch_size, image_size, cap_seq_size, cap_emb_dim, cap_drop_prob, seed=2024 + rank)
-    if len(have) != len(dirs):
+    if len(have) != len(dirs) or not dirs:
         missing = sorted(set(dirs) - set(have))
-        raise FileNotFoundError(f"MDS directories without index.json: {missing}")
+        raise FileNotFoundError(f"MDS directories without index.json: {missing} (pass datadir='synthetic' for random latents)")
     dataset = StreamingLatentsDataset(streams=dirs, shuffle=shuffle, image_size=image_size, cap_seq_size=cap_seq_size,
                                       cap_emb_dim=cap_emb_dim, cap_drop_prob=cap_drop_prob, batch_size=batch_size)
     device = dataloader_kwargs.pop("device", "cuda" if torch.cuda.is_available() else "cpu")

@@ -46,7 +46,19 @@ def _source_hash() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every .hip under csrc/ for gfx950 and link libmicrodit_hip.so in-tree (idempotent)."""
+    """Compile every .hip under csrc/ for gfx950 and link libmicrodit_hip.so in-tree (idempotent).  Serialised across
+    processes by a file lock: with one process per GPU every rank may find the library stale at the same moment."""
+    import fcntl
+    os.makedirs(os.path.join(_CSRC, "build"), exist_ok=True)
+    with open(os.path.join(_CSRC, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     want = _source_hash()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH):
         with open(_HASH_PATH) as fh:
@@ -70,10 +82,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out.strip():
             sys.stderr.write(out.decode(errors="replace"))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
     with open(_HASH_PATH, "w") as fh:
         fh.write(want)
     return LIB_PATH
@@ -166,10 +179,13 @@ class AttnArgs(Structure):
 
 class AdamWArgs(Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow", c_void_p),
-                ("sumsq", c_void_p), ("n", c_int64),
+                ("sumsq", c_void_p), ("g_bf16", c_void_p), ("ema", c_void_p), ("n", c_int64),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
                 ("bias_corr1", c_float), ("bias_corr2", c_float), ("max_norm", c_float), ("grad_scale", c_float),
-                ("zero_grad", c_int32)]
+                ("ema_smoothing", c_float), ("zero_grad", c_int32), ("ema_mode", c_int32)]
+
+
+SUMSQ_PARTIALS = 1024    # MD_SUMSQ_PARTIALS
 
 
 _sig("md_gemm_bf16", POINTER(GemmArgs), P)
@@ -203,7 +219,8 @@ _sig("md_patchify", P, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_timestep_embed", P, P, I64, I32, P)
 _sig("md_unpatchify", P, P, I64, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_edm_loss", P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I32, F32, P)
-_sig("md_sumsq", P, I64, P, P)
+_sig("md_sumsq", P, I32, I64, P, P)
+_sig("md_sumsq_finish", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_debug_tr_probe", P, P, P)
 _sig("md_debug_mfma_probe", P, P, P, P)

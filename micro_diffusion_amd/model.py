@@ -8,6 +8,7 @@ Sampling (`edm_sampler_loop` / `generate`) is inference-only glue around the sam
 from __future__ import annotations
 
 from functools import partial
+import warnings
 from types import SimpleNamespace
 from typing import Optional
 
@@ -285,17 +286,17 @@ def create_latent_diffusion(vae_name: str = "stabilityai/stable-diffusion-xl-bas
     vae = text_encoder = tokenizer = None
     try:
         from diffusers import AutoencoderKL  # type: ignore
+    except ImportError:
+        warnings.warn(f"diffusers is not installed: VAE '{vae_name}' replaced by a stub (training on precomputed latents only)")
+        vae = _FrozenStub(f"VAE '{vae_name}'")
+    else:       # a real load error (bad name, no network) must surface, not turn into a stub with a made-up scaling factor
         vae = AutoencoderKL.from_pretrained(vae_name, subfolder=None if vae_name == "ostris/vae-kl-f8-d16" else "vae",
                                             torch_dtype=DATA_TYPES[dtype])
-    except Exception:
-        vae = _FrozenStub(f"VAE '{vae_name}'")
-    try:
-        from .text import UniversalTextEncoder, UniversalTokenizer  # optional, needs open_clip / transformers weights
-        text_encoder = UniversalTextEncoder(text_encoder_name, dtype=dtype, pretrained=True)
-        tokenizer = UniversalTokenizer(text_encoder_name)
-    except Exception:
-        text_encoder = _FrozenStub(f"text encoder '{text_encoder_name}'")
-        tokenizer = _FrozenStub(f"tokenizer '{text_encoder_name}'")
+    # The reference's UniversalTextEncoder / UniversalTokenizer (utils.py:429-598: open_clip / T5 / CLIP wrappers around
+    # frozen third-party models) are outside the training hot path and are NOT built here (out of
+    # scope): generate(prompt=...) needs caller-supplied embeddings; training reads precomputed caption latents.
+    text_encoder = _FrozenStub(f"text encoder '{text_encoder_name}' (wrapper not built: pass precomputed caption embeddings)")
+    tokenizer = _FrozenStub(f"tokenizer '{text_encoder_name}' (wrapper not built)")
     return LatentDiffusion(dit=dit, vae=vae, text_encoder=text_encoder, tokenizer=tokenizer,
                            precomputed_latents=precomputed_latents, dtype=dtype, latent_res=latent_res, p_mean=p_mean,
                            p_std=p_std, train_mask_ratio=train_mask_ratio)

@@ -70,30 +70,51 @@ class LRSchedule:
 
 
 class FusedAdamW:
-    """torch.optim.AdamW semantics (train.py:39-43) on the DiT's flat buffers, one HIP kernel per step."""
+    """torch.optim.AdamW semantics (train.py:39-43) on the DiT's flat buffers, one HIP kernel per step; optionally the
+    EMA of the weights the res-512 configs name (configs/res_512_pretrain.yaml:4-9: smoothing 0.99975, every batch, from
+    batch 25000 on) folded into the same pass."""
 
-    def __init__(self, dit, lr: float = 2.4e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1):
+    MAX_BUCKETS = 64      # per-bucket partial sums of the gradient norm (data-parallel exchange), MD_SUMSQ_PARTIALS floats each
+
+    def __init__(self, dit, lr: float = 2.4e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.1,
+                 ema_smoothing: Optional[float] = None, ema_start: int = 0):
         self.dit = dit
         f = dit.flat_buffers()
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.m = torch.zeros_like(f["p"])
         self.v = torch.zeros_like(f["p"])
         self.sumsq = torch.zeros(1, device=f["p"].device)
+        self.partials = torch.zeros(self.MAX_BUCKETS * hip.SUMSQ_PARTIALS, device=f["p"].device)
         self.step_count = 0
+        self.ema_smoothing, self.ema_start = ema_smoothing, int(ema_start)
+        self.ema = torch.zeros_like(f["p"]) if ema_smoothing is not None else None
+        self.ema_live = False
 
-    def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0) -> None:
+    def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0, g_bf16: Optional[torch.Tensor] = None,
+             norm_partials: int = 0) -> None:
+        """`g_bf16`: take the gradients from this bf16 flat buffer (data-parallel exchange buffer) instead of the fp32
+        accumulators.  `norm_partials` > 0: that many per-bucket partial sums of squares are already in self.partials."""
         f = self.dit.flat_buffers()
         L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
         self.step_count += 1
         b1, b2 = self.betas
         ss = None
         if max_norm and max_norm > 0:
-            self.sumsq.zero_()
-            hip.check(L.md_sumsq(f["g"].data_ptr(), f["total"], self.sumsq.data_ptr(), st), "md_sumsq")
+            if norm_partials <= 0:
+                src = g_bf16 if g_bf16 is not None else f["g"]
+                hip.check(L.md_sumsq(src.data_ptr(), 1 if g_bf16 is not None else 0, f["total"], self.partials.data_ptr(), st), "md_sumsq")
+                norm_partials = hip.SUMSQ_PARTIALS
+            hip.check(L.md_sumsq_finish(self.partials.data_ptr(), norm_partials, self.sumsq.data_ptr(), st), "md_sumsq_finish")
             ss = self.sumsq.data_ptr()
+        ema_mode = 0
+        if self.ema is not None and self.step_count > self.ema_start:
+            ema_mode = 2 if self.ema_live else 1          # first EMA batch: ema <- weights (the EMA model starts as a copy)
+            self.ema_live = True
         a = hip.AdamWArgs(f["p"].data_ptr(), f["g"].data_ptr(), self.m.data_ptr(), self.v.data_ptr(), f["s"].data_ptr(), ss,
+                          g_bf16.data_ptr() if g_bf16 is not None else None, self.ema.data_ptr() if self.ema is not None else None,
                           f["total"], self.lr if lr is None else lr, b1, b2, self.eps, self.weight_decay,
-                          1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale, 1)
+                          1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale,
+                          self.ema_smoothing or 0.0, 1, ema_mode)
         hip.check(L.md_adamw_step(byref(a), st), "md_adamw_step")
         self.dit.mark_shadow_fresh()
 
@@ -102,22 +123,42 @@ class FusedAdamW:
         return self.sumsq.sqrt()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count}
+        sd = {"m": self.m, "v": self.v, "step": self.step_count}
+        if self.ema is not None:
+            sd["ema"], sd["ema_live"] = self.ema, self.ema_live
+        return sd
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])
+        if self.ema is not None and "ema" in sd:
+            self.ema.copy_(sd["ema"])
+            self.ema_live = bool(sd.get("ema_live", True))
 
 
 class GradSync:
-    """Overlapped data-parallel gradient averaging: contiguous segments of the flat fp32 gradient buffer are
-    all-reduced (RCCL, async: RCCL's own stream) as soon as the engine reports their backward as enqueued."""
+    """Overlapped data-parallel gradient averaging (the reference's FSDP gradient reduction, configs/*.yaml fsdp_config).
 
-    def __init__(self, dit, process_group=None):
+    As soon as the engine reports the backward of a segment (final layer, one DiT block, ...) as enqueued, that segment of
+    the flat gradient buffer is handed to RCCL (torch.distributed, backend "nccl" = RCCL over xGMI; async: the collective
+    runs on RCCL's own stream behind an event on the compute stream) while the remaining backward kernels keep the CUs busy.
+    Exchange formats:
+      "bf16"  the segment is cast into a bf16 staging buffer (one HIP kernel) and THAT is all-reduced: 2.33 GB instead of
+              4.66 GB per step for XL/2 (FSDP's default mixed precision reduces gradients in the low precision too, SURVEY.md
+              C.7); the optimiser kernel reads the reduced bf16 gradients and still zeroes the fp32 accumulators;
+      "fp32"  in-place all-reduce of the fp32 accumulators (gloo / parity runs).
+    The squared norm of every reduced segment is taken on a side stream right behind its collective (deterministic partial
+    sums, md_sumsq), so the clip coefficient needs no extra pass after the last bucket and is bit-identical on all ranks."""
+
+    def __init__(self, dit, process_group=None, exchange: str = "auto"):
         self.dit = dit
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if exchange == "auto":
+            exchange = "bf16" if (self.world > 1 and dist.get_backend(process_group) == "nccl") else "fp32"
+        assert exchange in ("bf16", "fp32")
+        self.exchange = exchange
         f = dit.flat_buffers()
         # segment prefix -> [start, end) in the flat buffer (table order is contiguous per module)
         import numpy as np
@@ -133,16 +174,39 @@ class GradSync:
             r[0], r[1] = min(r[0], o), max(r[1], o + n)
         self.pending = []
         self.active = False
+        self.buckets = 0                 # buckets handed over in the current step (= partial-sum slots in use)
+        self.norm_partials: Optional[torch.Tensor] = None     # set by the Trainer: FusedAdamW.partials
+        self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.world > 1) else None
+        self.side = torch.cuda.Stream(device=f["g"].device) if (self.world > 1 and f["g"].is_cuda) else None
+
+    def describe(self) -> str:
+        if self.world == 1:
+            return "none (single rank)"
+        return f"{self.exchange} all-reduce per backward segment ({len(self.ranges) + 2} buckets), overlapped with backward"
+
+    def _exchange(self, lo: int, hi: int) -> None:
+        f = self.dit.flat_buffers()
+        g = f["g"][lo:hi]
+        if self.exchange == "bf16":
+            buf = self.gbf[lo:hi]
+            hip.check(hip.lib().md_cast_f32_bf16(g.data_ptr(), buf.data_ptr(), hi - lo, None, torch.cuda.current_stream().cuda_stream), "cast")
+        else:
+            buf = g
+        work = dist.all_reduce(buf, group=self.pg, async_op=True)
+        slot = self.buckets
+        self.buckets += 1
+        if self.norm_partials is not None and self.side is not None and slot < FusedAdamW.MAX_BUCKETS:
+            with torch.cuda.stream(self.side):
+                work.wait()              # stream-side dependency under NCCL; the norm overlaps the remaining backward
+                hip.check(hip.lib().md_sumsq(buf.data_ptr(), 1 if self.exchange == "bf16" else 0, hi - lo,
+                                             self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS, self.side.cuda_stream), "md_sumsq")
+        self.pending.append(work)
 
     def on_segment(self, name: str) -> None:
         if not self.active or self.world == 1:
             return
-        if name == "rest":
-            for lo, hi in self._rest_ranges():
-                self.pending.append(dist.all_reduce(self.dit.flat_buffers()["g"][lo:hi], group=self.pg, async_op=True))
-            return
-        lo, hi = self.ranges[name]
-        self.pending.append(dist.all_reduce(self.dit.flat_buffers()["g"][lo:hi], group=self.pg, async_op=True))
+        for lo, hi in (self._rest_ranges() if name == "rest" else [tuple(self.ranges[name])]):
+            self._exchange(lo, hi)
 
     def _rest_ranges(self):
         """'rest' = everything that is not a DiT block or the final layer; not contiguous (front end precedes the
@@ -158,18 +222,26 @@ class GradSync:
             out.append((cur, total))
         return out
 
-    def finish(self) -> None:
+    def finish(self) -> int:
+        """Wait for every bucket; returns the number of norm partial-sum slots filled (0 = the optimiser takes the norm itself)."""
         for w in self.pending:
             w.wait()
         self.pending = []
+        n = self.buckets if (self.norm_partials is not None and self.side is not None and 0 < self.buckets <= FusedAdamW.MAX_BUCKETS) else 0
+        if self.side is not None and self.buckets:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.buckets = 0
+        return n
 
 
 class Trainer:
     def __init__(self, model, optimizer: FusedAdamW, schedule: Optional[LRSchedule] = None, clip_norm: float = 0.0,
-                 microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None):
+                 microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None,
+                 exchange: str = "auto"):
         self.model, self.opt, self.schedule, self.clip_norm = model, optimizer, schedule, clip_norm
         self.microbatch_size = microbatch_size
-        self.sync = GradSync(model.dit, process_group)
+        self.sync = GradSync(model.dit, process_group, exchange=exchange)
+        self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
         model.dit._on_segment = self.sync.on_segment
         self.batches_seen = 0
@@ -191,9 +263,10 @@ class Trainer:
             (loss * w).backward()
             total = loss.detach() * w if total is None else total + loss.detach() * w
         self.sync.active = False
-        self.sync.finish()
+        slots = self.sync.finish()
         fac = self.schedule.factor(self.batches_seen) if self.schedule is not None else 1.0
-        self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world)
+        self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
+                      g_bf16=self.sync.gbf if self.world > 1 else None, norm_partials=slots * hip.SUMSQ_PARTIALS)
         self.batches_seen += 1
         return total
 

@@ -416,32 +416,60 @@ def test_edm_patchify_loss(hip, masked):
 
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_adamw_clip(hip):
+    """clip_grad_norm_ + torch.optim.AdamW (train.py:39-43,85-86) vs md_sumsq / md_sumsq_finish / md_adamw_step, with the
+    gradient taken from the fp32 accumulators and from a bf16 exchange buffer, and the EMA of the weights
+    (configs/res_512_pretrain.yaml:4-9) folded in: ema <- weights on its first batch, s * ema + (1 - s) * weights after."""
     torch.manual_seed(4)
     L, st = hip.lib(), hip.stream_ptr()
     n = 4096 * 33
-    p = torch.randn(n, device=DEV)
-    pref = torch.nn.Parameter(p.clone())
-    opt = torch.optim.AdamW([pref], lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
-    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
-    ss = torch.zeros(1, device=DEV)
-    for step in range(1, 5):
-        g = torch.randn(n, device=DEV) * (0.01 if step == 3 else 1.0)   # step 3: below the clip threshold
-        pref.grad = g.clone()
-        torch.nn.utils.clip_grad_norm_([pref], 0.25 if step != 3 else 1e9)
-        opt.step()
-        gw = g.clone()
-        ss.zero_()
-        hip.check(L.md_sumsq(gw.data_ptr(), n, ss.data_ptr(), st), "sumsq")
-        a = hip.AdamWArgs(p.data_ptr(), gw.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), ss.data_ptr(), n,
-                          2.4e-4, 0.9, 0.999, 1e-8, 0.1, 1 - 0.9 ** step, 1 - 0.999 ** step,
-                          0.25 if step != 3 else 1e9, 1.0, 1)
-        hip.check(L.md_adamw_step(byref(a), st), "adamw")
+    for g_bf16 in (False, True):
+        p = torch.randn(n, device=DEV)
+        pref = torch.nn.Parameter(p.clone())
+        opt = torch.optim.AdamW([pref], lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+        ema = torch.zeros(n, device=DEV)
+        ema_ref = None
+        ss = torch.zeros(1, device=DEV)
+        part = torch.zeros(hip.SUMSQ_PARTIALS, device=DEV)
+        for step in range(1, 5):
+            g = torch.randn(n, device=DEV) * (0.01 if step == 3 else 1.0)   # step 3: below the clip threshold
+            if g_bf16:
+                g = bf(g).float()
+            pref.grad = g.clone()
+            torch.nn.utils.clip_grad_norm_([pref], 0.25 if step != 3 else 1e9)
+            opt.step()
+            gw = g.clone()
+            gb = bf(g) if g_bf16 else None
+            src = gb if g_bf16 else gw
+            hip.check(L.md_sumsq(src.data_ptr(), 1 if g_bf16 else 0, n, part.data_ptr(), st), "sumsq")
+            hip.check(L.md_sumsq_finish(part.data_ptr(), hip.SUMSQ_PARTIALS, ss.data_ptr(), st), "sumsq_finish")
+            ema_mode = 0 if step == 1 else (1 if step == 2 else 2)
+            a = hip.AdamWArgs(p.data_ptr(), gw.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), ss.data_ptr(),
+                              gb.data_ptr() if g_bf16 else None, ema.data_ptr(), n,
+                              2.4e-4, 0.9, 0.999, 1e-8, 0.1, 1 - 0.9 ** step, 1 - 0.999 ** step,
+                              0.25 if step != 3 else 1e9, 1.0, 0.99, 1, ema_mode)
+            hip.check(L.md_adamw_step(byref(a), st), "adamw")
+            torch.cuda.synchronize()
+            assert abs(ss.item() - (g.double() ** 2).sum().item()) < 1e-5 * (g.double() ** 2).sum().item()
+            assert torch.allclose(p, pref.detach(), rtol=1e-5, atol=1e-6), (p - pref.detach()).abs().max()
+            assert gw.abs().max() == 0
+            assert torch.equal(shadow, p.to(torch.bfloat16))
+            if ema_mode == 1:
+                ema_ref = pref.detach().clone()
+            elif ema_mode == 2:
+                ema_ref = 0.99 * ema_ref + 0.01 * pref.detach()
+            if ema_ref is not None:
+                assert torch.allclose(ema, ema_ref, rtol=1e-5, atol=1e-6)
+    # determinism of the norm: bit-identical partial sums run to run
+    g = torch.randn(1 << 22, device=DEV)
+    outs = []
+    for _ in range(3):
+        hip.check(L.md_sumsq(g.data_ptr(), 0, g.numel(), part.data_ptr(), st), "sumsq")
+        hip.check(L.md_sumsq_finish(part.data_ptr(), hip.SUMSQ_PARTIALS, ss.data_ptr(), st), "sumsq_finish")
         torch.cuda.synchronize()
-        assert abs(ss.item() - (g.double() ** 2).sum().item()) < 1e-3 * (g.double() ** 2).sum().item()
-        assert torch.allclose(p, pref.detach(), rtol=1e-5, atol=1e-6), (p - pref.detach()).abs().max()
-        assert gw.abs().max() == 0
-        assert torch.equal(shadow, p.to(torch.bfloat16))
+        outs.append(ss.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
 # ------------------------------------------------------------------------------------------------ MoE layer, routing injected

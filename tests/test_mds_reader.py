@@ -257,12 +257,19 @@ def test_loader_coin_rate_and_reader_errors_surface(shards, tmp_path):
     with pytest.raises(mds.MDSError) as ei:
         list(mdata.LatentsLoader(bad, 4, device="cpu", rank=0, world_size=1))
     assert ei.value.code == mds.SIZE_MISMATCH
-    # factory: MDS dirs present -> reader; absent -> synthetic (needs a device generator, so only type-checked here)
+    # factory: MDS dirs present -> reader; a missing path raises (never silently random data); random latents only
+    # on explicit request (datadir="synthetic"; the generator needs a device, so that branch is exercised on the GPU box)
     ld = mdata.build_streaming_latents_dataloader([d], batch_size=5, image_size=256, cap_drop_prob=0.1, shuffle=True,
                                                   drop_last=True, num_workers=2, prefetch_factor=2, device="cpu")
     assert isinstance(ld, mdata.LatentsLoader) and len(ld) == 10 and ld.dataset.cap_drop_prob == 0.1
     with pytest.raises(FileNotFoundError):
         mdata.build_streaming_latents_dataloader([d, str(tmp_path / "missing")], batch_size=5)
+    with pytest.raises(FileNotFoundError):
+        mdata.build_streaming_latents_dataloader(str(tmp_path / "missing"), batch_size=5)
+    with pytest.raises(ValueError):            # fewer samples than one batch: would spin forever with loop=True
+        mdata.LatentsLoader(mdata.StreamingLatentsDataset(streams=[d], shuffle=False, image_size=256, cap_seq_size=77, cap_emb_dim=1024,
+                                                          batch_size=64), 64,
+                            device="cpu", rank=0, world_size=1)
 
 
 def test_loader_resume_mid_epoch(shards):

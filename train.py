@@ -34,6 +34,10 @@ def train(cfg: dict):
     model = mdcfg.instantiate(cfg["model"])
     model.dit.to("cuda")
     model.train()
+    # Same init on every rank (built under the shared seed, there is no weight broadcast), then rank-wise noise: Composer's
+    # Trainer re-seeds each rank with seed + rank after the model exists, so the ranks draw different
+    # sigma / eps / mask noise for their shards of the global batch.
+    torch.manual_seed(cfg["seed"] + rank)
     carried_opt = None
     if cfg["trainer"].get("load_path"):
         ckpt = torch.load(cfg["trainer"]["load_path"], map_location="cuda")
@@ -84,6 +88,11 @@ def train(cfg: dict):
         trainer.batches_seen = start
         if ck.get("loader") is not None and hasattr(loader, "load_state_dict"):
             loader.load_state_dict(ck["loader"])
+        # the noise stream must not restart from the initial seed: fold the position into it (every rank can do this
+        # without having saved its own generator state; rank 0's exact state is restored when present)
+        torch.manual_seed(cfg["seed"] + rank + 1000003 * start)
+        if rank == 0 and ck.get("rng_cuda") is not None:
+            torch.cuda.set_rng_state(ck["rng_cuda"].cpu())
         if rank == 0:
             print(json.dumps({"resumed_from": latest, "batch": start}), flush=True)
     t_last = time.time()
@@ -98,10 +107,11 @@ def train(cfg: dict):
                               "samples_per_sec": ds["train_batch_size"] * log_every / dt}), flush=True)
         if rank == 0 and folder and save_every and (step + 1) % save_every == 0:
             os.makedirs(folder, exist_ok=True)
+            tmp = os.path.join(folder, "latest.pt.tmp")
             torch.save({"state": {"model": {"dit." + k: v for k, v in model.dit.state_dict().items()}},
-                        "optimizer": opt.state_dict(), "batch": step + 1,
-                        "loader": loader.state_dict() if hasattr(loader, "state_dict") else None},
-                       os.path.join(folder, "latest.pt"))
+                        "optimizer": opt.state_dict(), "batch": step + 1, "rng_cuda": torch.cuda.get_rng_state(),
+                        "loader": loader.state_dict() if hasattr(loader, "state_dict") else None}, tmp)
+            os.replace(tmp, os.path.join(folder, "latest.pt"))      # never leave a truncated latest.pt behind
     return trainer
 
 
