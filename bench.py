@@ -252,8 +252,9 @@ def main():
             head.model(part)[0].backward()
         torch.cuda.synchronize()
         prof, eng.gemm_profile = eng.gemm_profile, None
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
-        tot_fl = sum(f for _, _, f, _ in prof)
+        tot_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+        tot_fl = sum(r[2] for r in prof)
+        tot_by = sum(r[4] for r in prof)
         n = len(prof)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         traffic, tinfo = gemm_traffic()
@@ -262,7 +263,9 @@ def main():
                            "kernel": "md_gemm_bf16 family (gemm_bf16_pp_kernel + gemm_bf16_kernel + gemm_bf16_dma_kernel)",
                            "launches": n, "avg_launch_us": tot_ms * 1e3 / n, "gflop_per_launch": tot_fl / n / 1e9,
                            "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None,
-                           "traffic_source": tinfo}
+                           "algorithmic_bytes_per_launch": tot_by / n,
+                           "traffic_over_algorithmic": (traffic / (tot_by / n)) if traffic else None,
+                           "traffic_source": ({k: v for k, v in tinfo.items() if k != "per_kernel"} if tinfo else None)}
     if world == 1 and not args.no_other_stages:
         # ---- the YAML microbatch (the per-rank shape of an 8-GPU run) on the same model
         head.trainer.microbatch_size = 256

@@ -147,7 +147,8 @@ typedef struct md_attn_args {
     int64_t ldq, ldk, ldv, ldo, sq, sk, sv, so;
     int64_t lddq, lddk, lddv, lddo, sdq, sdk, sdv, sdo;
     float scale;
-    int32_t hd; /* 32 or 64 */
+    int32_t hd;        /* 32 or 64 */
+    int32_t bwd_split; /* 0 = the library picks (one fused backward launch for Sq, Skv <= 256); 1 = force the dQ + dK/dV pair (tests) */
 } md_attn_args;
 
 int md_attn_fwd(const md_attn_args* a, hipStream_t stream);

@@ -358,6 +358,198 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward for the training shapes (Sq, Skv <= 256): ONE workgroup per (batch, head) stages Q, dO, K, V into LDS once,
+// computes delta = rowsum(dO * O) in place, and every wave then plays both roles of the two kernels above on its 32 rows —
+// dQ for query rows w * 32.. (looping over the key tiles in LDS) and dK / dV for key rows w * 32.. (looping over the query
+// tiles) — so each of Q, K, V, dO, O is read from HBM once and delta / lse never round-trip through memory between two
+// launches (the split kernels read Q, K, V, dO twice: 12 tensor passes against 8; these shapes are HBM-bound).
+// SQP / SKP = padded row counts (multiples of 32) the LDS image is sized for.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD, int SQP, int SKP>
+__global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * SQP + 2 * SKP) * PK + 2 * SQP * 4];
+    unsigned char* sQ = smem;
+    unsigned char* sdO = smem + SQP * PK;
+    unsigned char* sK = smem + 2 * SQP * PK;
+    unsigned char* sV = sK + SKP * PK;
+    float* sLse = reinterpret_cast<float*>(sV + SKP * PK);
+    float* sDlt = sLse + SQP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.y, h = blockIdx.x;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD;
+    const int nq32 = (int)((p.Sq + 31) / 32), nk32 = (int)((p.Skv + 31) / 32);
+
+    stage_tile<HD>(sQ, PK, Q, p.ldq, 0, p.Sq, nq32 * 32, tid, nthreads);
+    stage_tile<HD>(sdO, PK, dO, p.lddo, 0, p.Sq, nq32 * 32, tid, nthreads);
+    stage_tile<HD>(sK, PK, K, p.ldk, 0, p.Skv, nk32 * 32, tid, nthreads);
+    stage_tile<HD>(sV, PK, V, p.ldv, 0, p.Skv, nk32 * 32, tid, nthreads);
+    // delta[q] = sum_d dO[q, d] * O[q, d] and lse[q]: 8 lanes per row (HD / 8 chunks of 16 bytes)
+    {
+        constexpr int CPR = HD / 8;
+        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
+        for (int task = tid; task < nq32 * 32 * CPR; task += nthreads) {
+            const int r = task / CPR, c = task % CPR;
+            float d = 0.f;
+            if (r < p.Sq) {
+                const bf16x8 ov = ld_bf16x8(O + (int64_t)r * p.ldo + c * 8);
+                const bf16x8 gv = ld_bf16x8(dO + (int64_t)r * p.lddo + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += bf2f(ov[e]) * bf2f(gv[e]);
+            }
+#pragma unroll
+            for (int o = CPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);       // the CPR lanes of a row are adjacent
+            if (c == 0) {
+                sDlt[r] = d;
+                sLse[r] = r < p.Sq ? LSE[r] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- role 1: dQ for query rows wave * 32 ..
+    if (wave < nq32) {
+        const unsigned char* myQ = sQ + wave * 32 * PK;
+        const unsigned char* mydO = sdO + wave * 32 * PK;
+        const int64_t q = (int64_t)wave * 32 + (lane & 31);
+        bf16x8 qf[HD / 16], dof[HD / 16];
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            qf[s] = row_frag(myQ, PK, s * 16, lane);
+            dof[s] = row_frag(mydO, PK, s * 16, lane);
+        }
+        const float lse = sLse[wave * 32 + (lane & 31)], dlt = sDlt[wave * 32 + (lane & 31)];
+        f32x16 dqacc[HD / 32];
+#pragma unroll
+        for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
+        for (int j = 0; j < nk32; ++j) {
+            const unsigned char* tK = sK + j * 32 * PK;
+            const unsigned char* tV = sV + j * 32 * PK;
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t key = (int64_t)j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
+                sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(sacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di)
+                    dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
+            }
+        }
+        if (q < p.Sq) {
+            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+            store_rows<HD>(dQ, dqacc, 1.f, lane);
+        }
+    }
+    // ---------------- role 2: dK, dV for key rows wave * 32 ..
+    if (wave < nk32) {
+        const unsigned char* myK = sK + wave * 32 * PK;
+        const unsigned char* myV = sV + wave * 32 * PK;
+        const int64_t key = (int64_t)wave * 32 + (lane & 31);
+        bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            kf[s] = row_frag(myK, PK, s * 16, lane);
+            vf[s] = row_frag(myV, PK, s * 16, lane);
+        }
+        f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+        for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[di][r] = 0.f;
+                dvacc[di][r] = 0.f;
+            }
+        for (int i = 0; i < nq32; ++i) {
+            const unsigned char* tQ = sQ + i * 32 * PK;
+            const unsigned char* tdO = sdO + i * 32 * PK;
+            const float* tLse = sLse + i * 32;
+            const float* tDlt = sDlt + i * 32;
+            f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
+                sacc[r] = pr;                                           // P
+                dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc, 8 * sp);
+                const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di) {
+                    dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
+                    dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+                }
+            }
+        }
+        if (key < p.Skv) {
+            bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
+            bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+            store_rows<HD>(dK, dkacc, 1.f, lane);
+            store_rows<HD>(dV, dvacc, 1.f, lane);
+        }
+    }
+}
+
+// Padded row-count bucket of the fused backward: 64, 96 or 256 (0 = not covered)
+inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 256 ? 256 : 0; }
+
+template <int HD>
+bool launch_bwd_fused(const md_attn_args* a, hipStream_t stream) {
+    const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
+    if (!bq || !bk) return false;
+    const dim3 grid((unsigned)a->H, (unsigned)a->B);
+#define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
+    if (bq == 64 && bk == 64) FUSED(64, 64);
+    else if (bq == 64 && bk == 96) FUSED(64, 96);
+    else if (bq == 96 && bk == 64) FUSED(96, 64);
+    else if (bq == 96 && bk == 96) FUSED(96, 96);
+    else if (bq == 256 && bk == 96) FUSED(256, 96);
+    else if (bq == 256 && bk == 256) FUSED(256, 256);
+    else if (bq == 64 && bk == 256) FUSED(64, 256);
+    else if (bq == 256 && bk == 64) FUSED(256, 64);
+    else FUSED(96, 256);
+#undef FUSED
+    return true;
+}
+
 inline int waves_for(int64_t S) {
     int64_t w = (S + 31) / 32;
     return (int)(w > 4 ? 4 : (w < 1 ? 1 : w));
@@ -386,6 +578,11 @@ extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
 extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
+    // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
+    if (a->bwd_split == 0 && (a->hd == 64 ? launch_bwd_fused<64>(a, stream) : launch_bwd_fused<32>(a, stream))) {
+        MD_LAUNCH_CHECK();
+        return 0;
+    }
     const int nwq = waves_for(a->Sq), nwk = waves_for(a->Skv);
     dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
     dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);

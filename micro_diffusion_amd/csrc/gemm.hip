@@ -597,7 +597,7 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
     int variant = a->variant;
     if (variant < MD_GEMM_AUTO || variant > MD_GEMM_PP256) return MD_BAD_ARG;
-    if (variant == MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
+    if (variant >= MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
     if (variant == MD_GEMM_AUTO) {
         if (md_gemm_pp_eligible(a) && tiles256 >= 192)
             variant = MD_GEMM_PP256;
@@ -616,12 +616,12 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (a->raster_group_n <= 0) {   // column-tiles per raster group: keep the group's B sub-panel (TN x K bf16) within ~2 MiB of the 4 MiB L2
         const int64_t ntn_ = (a->N + TMv - 1) / TMv;
         int64_t g = (2 << 20) / (TMv * kspan * 2);
-        if (variant == MD_GEMM_PP256 && g < 4) g = 4;   // an XCD's 32 concurrent tiles form an (32 / g) x g block
+        if (variant >= MD_GEMM_PP256 && g < 4) g = 4;   // an XCD's 32 concurrent tiles form an (32 / g) x g block
         if (g < 1) g = 1;
         if (g > ntn_) g = ntn_;
         a_copy.raster_group_n = (int)g;
     }
-    if (variant == MD_GEMM_PP256) return md_gemm_pp_launch(a, stream);
+    if (variant >= MD_GEMM_PP256) return md_gemm_pp_launch(a, stream);
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);
 #define LAUNCH(KERN, THREADS, ...)                                                                                          \

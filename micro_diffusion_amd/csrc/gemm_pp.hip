@@ -459,7 +459,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     PP_STAGE(0, 1); PP_STAGE(1, 1);
     PP_VMCNT(8);                                   // A0, B0 of k-tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
+    // Group 1 runs one barrier behind group 0: two barriers per phase (load | compute) enforce strict alternation of the
+    // groups' MFMA halves.  (A one-barrier-per-phase variant — group 0 passing it before its load half, group 1 between its
+    // load and compute halves, so that no wave idles when its partner's half is the longer one — was correct and 5-10 %
+    // SLOWER on every shape: profiles/r2_gemm_pp256_one_vs_two_barriers.txt.)
+    if (wr == 1) __builtin_amdgcn_s_barrier();
 
 #define PP_READ_A(BUF, IH)                                                                                              \
     do {                                                                                                                \
@@ -504,7 +508,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     // in order) and a count of 8 here would wait for the prefetch just issued.
 #define PP_RAW_WAIT(EPI_PHASE)                                                                                          \
     do {                                                                                                                \
-        if (!((EPI_PHASE) && has_ops && epi_was)) { if (s_live) PP_VMCNT(8); else PP_VMCNT(0); }                        \
+        if (!((EPI_PHASE) && has_ops && epi_was)) {                                                                     \
+            if (!s_live) PP_VMCNT(0);                                                                                   \
+            else PP_VMCNT(8);                                                                                           \
+        }                                                                                                               \
     } while (0)
 #define PP_PIN_NONE() do { } while (0)
 #define PP_COMPUTE(Q, FB, PINS)                                                                                         \

@@ -86,7 +86,12 @@ class DiTEngine:
             self.gemm_log.append((a.variant, a.M, a.N, a.K, a.batch))
         if prof is not None:
             e1.record()
-            prof.append((e0, e1, 2.0 * a.M * a.N * a.K * a.batch, (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit)))
+            # algorithmic HBM bytes of the launch: both operands once, every output once (+ fused-epilogue operands)
+            out_b = 4 if a.mode in (hip.EPI_STORE_F32, hip.EPI_ACCUM_F32, hip.EPI_ATOMIC_F32) else 2
+            mn = a.M * a.N * a.batch
+            byt = 2.0 * (a.M * a.K + a.N * a.K) * a.batch + mn * out_b * a.ksplit
+            byt += mn * 2 * ((1 if a.C2 else 0) + (1 if a.res else 0) + (1 if a.aux else 0)) + (mn * 4 if a.mode == hip.EPI_ACCUM_F32 else 0)
+            prof.append((e0, e1, 2.0 * a.M * a.N * a.K * a.batch, (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit), byt))
 
     def lin_fwd(self, x, wname, out, M, N, K, *, ldx=None, ldc=None, mode=hip.EPI_STORE_BF16, act=0, res=None,
                 gate=None, ldg=0, rps=0, C2=None, ldc2=0, xoff=0, ooff=0, bias=True):
@@ -203,7 +208,7 @@ class DiTEngine:
         hd = self.cfg.head_dim
         return hip.AttnArgs(q, k, v, _p(o), _p(lse), _p(do), dq, dk, dv, _p(delta), B, H, Sq, Skv, ldq, ldk, ldv, hid,
                             Sq * ldq, Skv * ldk, Skv * ldv, Sq * hid, lddq, lddk, lddv, hid, Sq * lddq, Skv * lddk,
-                            Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd)
+                            Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd, 0)
 
     # ------------------------------------------------------------------------------------------ attention layers
     def _self_attn_fwd(self, pre, xin, B, S, dim, hid, heads, t):

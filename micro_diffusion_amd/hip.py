@@ -174,7 +174,7 @@ class AttnArgs(Structure):
                 ("sq", c_int64), ("sk", c_int64), ("sv", c_int64), ("so", c_int64),
                 ("lddq", c_int64), ("lddk", c_int64), ("lddv", c_int64), ("lddo", c_int64),
                 ("sdq", c_int64), ("sdk", c_int64), ("sdv", c_int64), ("sdo", c_int64),
-                ("scale", c_float), ("hd", c_int32)]
+                ("scale", c_float), ("hd", c_int32), ("bwd_split", c_int32)]
 
 
 class AdamWArgs(Structure):

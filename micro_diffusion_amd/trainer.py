@@ -89,6 +89,7 @@ class FusedAdamW:
         self.ema_smoothing, self.ema_start = ema_smoothing, int(ema_start)
         self.ema = torch.zeros_like(f["p"]) if ema_smoothing is not None else None
         self.ema_live = False
+        self.last_grad_scale = 1.0
 
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0, g_bf16: Optional[torch.Tensor] = None,
              norm_partials: int = 0) -> None:
@@ -97,6 +98,7 @@ class FusedAdamW:
         f = self.dit.flat_buffers()
         L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
         self.step_count += 1
+        self.last_grad_scale = grad_scale
         b1, b2 = self.betas
         ss = None
         if max_norm and max_norm > 0:
@@ -119,8 +121,10 @@ class FusedAdamW:
         self.dit.mark_shadow_fresh()
 
     def grad_norm(self) -> torch.Tensor:
-        """||g||_2 of the last step before clipping (device scalar; valid after step() with max_norm > 0)."""
-        return self.sumsq.sqrt()
+        """||g||_2 of the last step's (rank-averaged) gradient before clipping (device scalar; valid after step() with
+        max_norm > 0).  The sum of squares is taken over the rank-SUMMED gradient; the 1 / world factor is applied here as in
+        the optimiser kernel."""
+        return self.sumsq.sqrt() * self.last_grad_scale
 
     def state_dict(self):
         sd = {"m": self.m, "v": self.v, "step": self.step_count}
@@ -178,6 +182,7 @@ class GradSync:
         self.norm_partials: Optional[torch.Tensor] = None     # set by the Trainer: FusedAdamW.partials
         self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.world > 1) else None
         self.side = torch.cuda.Stream(device=f["g"].device) if (self.world > 1 and f["g"].is_cuda) else None
+        self.host_bounce = self.world > 1 and f["g"].is_cuda and dist.get_backend(process_group) != "nccl"
 
     def describe(self) -> str:
         if self.world == 1:
@@ -192,15 +197,26 @@ class GradSync:
             hip.check(hip.lib().md_cast_f32_bf16(g.data_ptr(), buf.data_ptr(), hi - lo, None, torch.cuda.current_stream().cuda_stream), "cast")
         else:
             buf = g
-        work = dist.all_reduce(buf, group=self.pg, async_op=True)
+        if self.host_bounce:
+            # gloo (functional runs of several ranks on one GPU, CPU tests): reduce through host memory, synchronously
+            h = buf.float().cpu() if buf.dtype == torch.bfloat16 else buf.cpu()
+            dist.all_reduce(h, group=self.pg)
+            buf.copy_(h.to(buf.dtype))
+            work = None
+        else:
+            work = dist.all_reduce(buf, group=self.pg, async_op=True)
         slot = self.buckets
         self.buckets += 1
         if self.norm_partials is not None and self.side is not None and slot < FusedAdamW.MAX_BUCKETS:
+            if work is None:
+                self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                work.wait()              # stream-side dependency under NCCL; the norm overlaps the remaining backward
+                if work is not None:
+                    work.wait()          # stream-side dependency under NCCL; the norm overlaps the remaining backward
                 hip.check(hip.lib().md_sumsq(buf.data_ptr(), 1 if self.exchange == "bf16" else 0, hi - lo,
                                              self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS, self.side.cuda_stream), "md_sumsq")
-        self.pending.append(work)
+        if work is not None:
+            self.pending.append(work)
 
     def on_segment(self, name: str) -> None:
         if not self.active or self.world == 1:

@@ -1,4 +1,5 @@
-"""Attention fwd+bwd micro-benchmark at the MicroDiT-XL/2 shapes (B=256): python scripts/bench_attn.py [iters]"""
+"""Attention fwd+bwd micro-benchmark at the MicroDiT-XL/2 shapes: python scripts/bench_attn.py [iters] [batch]
+bwd: the fused single launch (Sq, Skv <= 256) against the dQ + dK/dV kernel pair; algorithmic HBM bytes / time alongside."""
 import os, sys, math
 from ctypes import byref
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,8 +7,10 @@ import torch
 from micro_diffusion_amd import hip
 L = hip.lib(); dev = "cuda"
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-shapes = [("mixer self  S=256 H=12", 256, 12, 256, 256, True), ("backbone self S=64 H=16", 256, 16, 64, 64, True),
-          ("cross Sq=64 Skv=77 H=16", 256, 16, 64, 77, False), ("caption self S=77 H=16", 256, 16, 77, 77, True)]
+BB = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+shapes = [("mixer self  S=256 H=12", BB, 12, 256, 256, True), ("backbone self S=64 H=16", BB, 16, 64, 64, True),
+          ("cross Sq=64 Skv=77 H=16", BB, 16, 64, 77, False), ("caption self S=77 H=16", BB, 16, 77, 77, True),
+          ("mixer cross 256x77 H=12", BB, 12, 256, 77, False)]
 for name, B, H, Sq, Skv, packed in shapes:
     hd, hid = 64, H * 64
     if packed:
@@ -24,13 +27,16 @@ for name, B, H, Sq, Skv, packed in shapes:
     a = hip.AttnArgs(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(), dq.data_ptr(),
                      dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Sq, Skv, ld[0], ld[1], ld[2], hid,
                      Sq * ld[0], Skv * ld[1], Skv * ld[2], Sq * hid, ld[0], ld[1], ld[2], hid, Sq * ld[0], Skv * ld[1],
-                     Skv * ld[2], Sq * hid, 1 / math.sqrt(hd), hd)
+                     Skv * ld[2], Sq * hid, 1 / math.sqrt(hd), hd, 0)
     st = hip.stream_ptr()
-    for fn, label, mult in ((L.md_attn_fwd, "fwd", 4), (L.md_attn_bwd, "bwd", 10)):
+    elt = B * H * hd * 2
+    for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd      ", 4, 0, elt * (2 * Sq + 2 * Skv)), (L.md_attn_bwd, "bwd fused", 10, 0, elt * (4 * Sq + 4 * Skv)),
+                                        (L.md_attn_bwd, "bwd split", 10, 1, elt * (4 * Sq + 4 * Skv))):
+        a.bwd_split = split
         fn(byref(a), st); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters): fn(byref(a), st)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / iters * 1e3
-        print(f"{name:26s} {label}: {us:8.1f} us  {mult*B*H*Sq*Skv*hd/us/1e6:7.1f} TFLOP/s", flush=True)
+        print(f"{name:26s} {label}: {us:8.1f} us  {mult*B*H*Sq*Skv*hd/us/1e6:7.1f} TFLOP/s  {byt/us/1e6:6.2f} TB/s algorithmic", flush=True)

@@ -22,7 +22,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); model(batch)[0].backward(); e1.record(); torch.cuda.synchronize()
 prof, eng.gemm_profile = eng.gemm_profile, None
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for a, b, fl, key in prof:
+for a, b, fl, key, _ in prof:
     r = agg[key]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
 tot = sum(r[1] for r in agg.values())
 print(f"microbatch {B}: total (with event overhead) {e0.elapsed_time(e1):.1f} ms, gemm {tot:.1f} ms, launches {len(prof)}")

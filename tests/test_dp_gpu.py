@@ -1,0 +1,110 @@
+"""Data parallelism on the real engine: two ranks (two processes sharing cuda:0, gloo rendezvous on
+127.0.0.1 — the same code path as one process per GPU over RCCL, minus the transport) each train one step on their half of a
+global batch through Trainer / GradSync / DiTEngine.backward's on_segment hand-off, and must end with the parameters and the
+gradient norm of a single rank that trains the whole batch with two microbatches on the same recorded noise.
+
+Reference behaviour being matched: train.py:50 (global batch split over ranks), configs/res_256_pretrain.yaml:111-118
+(microbatching + FSDP gradient averaging) — averaged-gradient data parallelism is numerically the same update.
+Tolerance: the two runs differ only in fp32 summation order (and, for the bf16 exchange, in one bf16 rounding of the
+reduced gradient): gradient norm within 1e-4 (2e-3 for bf16), updated parameters equal to 1e-5 absolute on >= 99.9 % of the
+elements (the first AdamW update is lr * g / (|g| + eps): elements with |g| ~ 1e-8 are the rest)."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SEED, BATCH = 61, 8
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(world_batch_slice, exchange, microbatch):
+    from oracle import microdit_ref as orc
+    from micro_diffusion_amd import dit as mdit
+    from micro_diffusion_amd.model import LatentDiffusion, _FrozenStub
+    from micro_diffusion_amd.trainer import FusedAdamW, LRSchedule, Trainer
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, SEED)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, BATCH, SEED + 1)
+    d = mdit.DiT(**cfg.__dict__)
+    d.load_state_dict(sd, strict=True)
+    model = LatentDiffusion(d.to("cuda"), _FrozenStub("vae"), _FrozenStub("te"), _FrozenStub("tok"), train_mask_ratio=0.75)
+    model.train()
+    lo, hi = world_batch_slice
+    calls = {"n": 0}
+
+    def noise_fn(B):                      # recorded draws, consumed microbatch by microbatch
+        a = lo + calls["n"] * B
+        calls["n"] += 1
+        return rnd[a:a + B].cuda(), epsn[a:a + B].cuda(), mnoise[a:a + B].cuda()
+    model._noise_fn = noise_fn
+    opt = FusedAdamW(model.dit, lr=2.4e-4)
+    tr = Trainer(model, opt, LRSchedule("constant", alpha=1.0), clip_norm=0.25, microbatch_size=microbatch, exchange=exchange)
+    part = {k: v[lo:hi].cuda() for k, v in batch.items()}
+    return model, opt, tr, part
+
+
+def _rank_main(rank, world, port, exchange, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = BATCH // world
+        model, opt, tr, part = _build((rank * per, (rank + 1) * per), exchange, per)
+        assert tr.world == world and tr.sync.exchange == exchange
+        loss = tr.train_step(part)
+        torch.cuda.synchronize()
+        flat = model.dit.flat_buffers()
+        # every rank must hold identical weights after the step (no broadcast ever happens)
+        mine = flat["p"].detach().cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        if rank == 0:
+            torch.save({"p": mine, "gnorm": float(opt.grad_norm().item()), "loss": float(loss), "ranks_identical": same,
+                        "buckets": len(tr.sync.ranges)}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["fp32", "bf16"])
+def test_two_ranks_match_one_rank(hip, exchange):
+    # ---- one rank, whole batch, two microbatches
+    model, opt, tr, part = _build((0, BATCH), "fp32", BATCH // 2)
+    tr.train_step(part)
+    torch.cuda.synchronize()
+    p1 = model.dit.flat_buffers()["p"].detach().cpu()
+    g1 = float(opt.grad_norm().item())
+    del model, opt, tr
+    torch.cuda.empty_cache()
+    # ---- two ranks, half the batch each
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rank0.pt")
+        ctx = mp.get_context("spawn")
+        port = _free_port()
+        procs = [ctx.Process(target=_rank_main, args=(r, 2, port, exchange, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+        codes = [p.exitcode for p in procs]
+        if exchange == "bf16" and any(codes) and not os.path.exists(out):
+            pytest.skip(f"this gloo build cannot all-reduce bf16 tensors (exit codes {codes}); the bf16 exchange runs over RCCL only")
+        assert codes == [0, 0], f"rank processes failed: {codes}"
+        r = torch.load(out)
+    assert r["ranks_identical"], "replicas diverged within one step"
+    assert r["buckets"] >= 4
+    tol_n, tol_frac = (1e-4, 1e-3) if exchange == "fp32" else (2e-3, 1e-2)
+    assert abs(r["gnorm"] - g1) <= tol_n * g1, (r["gnorm"], g1)
+    bad = ((r["p"] - p1).abs() > 1e-5).float().mean().item()
+    assert bad <= tol_frac, f"{bad:.2e} of the parameters differ by more than 1e-5 after one step"

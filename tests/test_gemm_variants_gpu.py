@@ -160,8 +160,9 @@ def test_pp256_refuses_what_it_cannot_run(hip):
     assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, variant=99, expect=None) == -1
 
 
+@pytest.mark.parametrize("variant", ["pp256"])
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0)])
-def test_pp256_race_screen(hip, akc, bkc):
+def test_pp256_race_screen(hip, akc, bkc, variant):
     """The ping-pong kernel orders its LDS ring with counted waits and barriers only: repeat a many-tile launch (several tiles
     per workgroup, short K so tile hand-overs dominate) and require bit-identical results, on an idle chip and while
     another stream streams through HBM (uneven arrival of the DMA pieces)."""
@@ -180,7 +181,7 @@ def test_pp256_race_screen(hip, akc, bkc):
                 for _ in range(4):
                     big.add_(1)
         hip.gemm(As, Bs, C, M, N, K, lda=lda, ldb=ldb, ldc=N, a_kcontig=akc, b_kcontig=bkc,
-                 mode=hip.EPI_STORE_F32 if f32 else hip.EPI_STORE_BF16, variant=hip.GEMM_PP256)
+                 mode=hip.EPI_STORE_F32 if f32 else hip.EPI_STORE_BF16, variant=hip.GEMM_VARIANT_NAMES[variant])
         torch.cuda.synchronize()
         outs.append(C)
     _close(outs[0], A.float() @ B.float().t(), rel=2e-3 if f32 else 2e-2, what="pp256")

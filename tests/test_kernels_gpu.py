@@ -123,8 +123,12 @@ def _attn_ref(q, k, v, H, hd):
 @pytest.mark.parametrize("B,H,Sq,Skv,hd,packed", [(3, 4, 64, 64, 64, True), (2, 12, 256, 256, 64, True),
                                                     (2, 16, 64, 77, 64, False), (2, 3, 77, 77, 64, True),
                                                     (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
-                                                    (1, 2, 1024, 1024, 64, True)])
-def test_attention(hip, B, H, Sq, Skv, hd, packed):
+                                                    (1, 2, 1024, 1024, 64, True), (2, 12, 256, 77, 64, False),
+                                                    (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True)])
+@pytest.mark.parametrize("bwd_split", [0, 1])
+def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
+    """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
+    kernel pair (the only path for longer sequences).  Both against torch fp32 autograd of the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
     L, st = hip.lib(), hip.stream_ptr()
     hid = H * hd
@@ -155,7 +159,7 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed):
     a = hip.AttnArgs(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(),
                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Sq, Skv,
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
-                     1.0 / math.sqrt(hd), hd)
+                     1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
     hip.check(L.md_attn_bwd(byref(a), st), "attn bwd")
     qr = q.float().clone().requires_grad_(True)
