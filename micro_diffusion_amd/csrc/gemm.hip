@@ -536,16 +536,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(md_gemm_arg
     timeline_finish(tl);
 }
 
-// out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses)
+// out[b][m][n] (+)= sum_s ws[b][s][m][n]   (ws slices are dense [M, N]; 16-byte accesses).  The slices are read once:
+// non-temporal loads, four independent slice loads in flight per thread (the one-load-per-iteration loop ran at 2.8 TB/s);
+// the summation order is fixed (deterministic weight gradients).
+__device__ __forceinline__ float4 nt_ld4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
                                                             int64_t sOut, int ksplit, int batch, int accumulate) {
-    const int64_t n4 = N / 4, per = M * n4, total = per * batch;
+    const int64_t n4 = N / 4, per = M * n4, total = per * batch, slice = M * N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / per, r = i % per, m = r / n4, c = (r % n4) * 4;
         const float* src = ws + ((b * ksplit) * M + m) * N + c;
-        float4 acc = *reinterpret_cast<const float4*>(src);
-        for (int s = 1; s < ksplit; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * M * N);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 4 <= ksplit; s += 4) {
+            const float4 v0 = nt_ld4(src + (int64_t)s * slice), v1 = nt_ld4(src + (int64_t)(s + 1) * slice);
+            const float4 v2 = nt_ld4(src + (int64_t)(s + 2) * slice), v3 = nt_ld4(src + (int64_t)(s + 3) * slice);
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; s < ksplit; ++s) {
+            const float4 v = nt_ld4(src + (int64_t)s * slice);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         float* dst = out + b * sOut + m * ldo + c;
@@ -563,7 +576,7 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
                                 int32_t batch, int32_t accumulate, hipStream_t stream) {
     if (!ws || !out || M <= 0 || N <= 0 || N % 4 || ldo % 4 || ksplit <= 0 || batch <= 0) return MD_BAD_ARG;
     int64_t grid = (M * (N / 4) * batch + 255) / 256;
-    if (grid > 4096) grid = 4096;
+    if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, M, N, ldo, sOut, ksplit, batch,
                        accumulate);
     MD_LAUNCH_CHECK();

@@ -60,3 +60,41 @@ def test_train_step_consumes_loader_batches(shards):
     assert isinstance(loader, mdata.LatentsLoader)
     losses = [tr.train_step(batch).item() for _, batch in zip(range(3), loader)]
     assert all(np.isfinite(losses)) and all(0.05 < l < 5 for l in losses), losses
+
+
+def test_train_py_eval_loop_and_ema(shards, tmp_path, capsys):
+    """train.py end to end on MDS shards: the eval loop (Composer's eval_forward / DistLoss at eval_mask_ratio 0,
+    model.py:217-229, utils.py:598-614, every `eval_interval`) and the EMA of the weights named by configs/res_512_*.yaml:4-9
+    (smoothing s, from `ema_start` on: ema <- weights on its first batch, then s * ema + (1 - s) * weights), fused into the
+    AdamW kernel."""
+    import json
+    import train as train_mod
+    d, _ = shards
+    target = "micro_diffusion.datasets.latents_loader.build_streaming_latents_dataloader"
+    cfg = {
+        "seed": 18,
+        "model": {"_target_": "micro_diffusion.models.model.create_latent_diffusion", "dit_arch": "MicroDiT_Tiny_2", "latent_res": 32,
+                  "in_channels": 4, "pos_interp_scale": 1.0, "dtype": "bfloat16", "precomputed_latents": True, "p_mean": -0.6,
+                  "p_std": 1.2, "train_mask_ratio": 0.75, "vae_name": "x", "text_encoder_name": "openclip:hf-hub:apple/DFN5B-CLIP-ViT-H-14-378"},
+        "optimizer": {"_target_": "torch.optim.AdamW", "lr": 1e-4, "weight_decay": 0.1, "eps": 1e-8, "betas": [0.9, 0.999]},
+        "scheduler": {"_target_": "composer.optim.ConstantScheduler", "alpha": 1.0},
+        "algorithms": {"gradient_clipping": {"clip_norm": 0.25, "clipping_type": "norm"}, "low_precision_layernorm": {"precision": "amp_bf16"},
+                       "ema": {"_target_": "diffusion.algorithms.ema.EMA", "half_life": None, "smoothing": 0.9, "update_interval": "1ba",
+                               "ema_start": "1ba"}},
+        "dataset": {"image_size": 256, "train_batch_size": 8, "eval_batch_size": 8, "cap_drop_prob": 0.1,
+                    "train": {"_target_": target, "datadir": [d], "drop_last": True, "shuffle": True},
+                    "eval": {"_target_": target, "datadir": [d], "drop_last": False, "shuffle": False}},
+        "trainer": {"max_duration": "4ba", "device_train_microbatch_size": 4, "eval_interval": "2ba", "save_interval": "0ba"},
+        "misc": {"log_interval": 1},
+    }
+    tr = train_mod.train(cfg)
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    evals = [l for l in lines if "metrics/eval/loss" in l]
+    assert [l["batch"] for l in evals] == [2, 4] and all(np.isfinite(l["metrics/eval/loss"]) and 0.05 < l["metrics/eval/loss"] < 5 for l in evals)
+    opt = tr.opt
+    assert opt.ema is not None and opt.ema_live
+    p = tr.model.dit.flat_buffers()["p"]
+    # after 4 steps with ema_start 1: ema(2) = p2, ema(3) = .9 p2 + .1 p3, ema(4) = .9 ema(3) + .1 p4 -> close to, but not equal to, p
+    rel = float((opt.ema - p).norm() / p.norm())
+    assert 0 < rel < 1e-2, rel
+    assert tr.model.training

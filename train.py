@@ -52,8 +52,16 @@ def train(cfg: dict):
         model.dit.load_state_dict(sd, strict=bool(cfg["trainer"].get("load_strict_model_weights", True)) and not ignore)
     ocfg = dict(cfg["optimizer"])
     ocfg.pop("_target_")
+    # EMA of the weights (configs/res_512_*.yaml:4-9, diffusion.algorithms.ema.EMA): folded into the AdamW kernel.  The
+    # reference's own train.py never instantiates it ("Algorithm ema not supported", train.py:87-88); here it is honoured.
+    ema_cfg = (cfg.get("algorithms") or {}).get("ema")
+    ema_kw = {}
+    if ema_cfg:
+        if ema_cfg.get("half_life") is not None or parse_batches(ema_cfg.get("update_interval", "1ba")) != 1:
+            raise ValueError("ema: only `smoothing` with update_interval 1ba is supported (the values the stage configs use)")
+        ema_kw = dict(ema_smoothing=float(ema_cfg["smoothing"]), ema_start=parse_batches(ema_cfg.get("ema_start", "0ba")))
     opt = FusedAdamW(model.dit, lr=ocfg["lr"], betas=tuple(ocfg.get("betas", (0.9, 0.999))), eps=ocfg.get("eps", 1e-8),
-                     weight_decay=ocfg.get("weight_decay", 0.0))
+                     weight_decay=ocfg.get("weight_decay", 0.0), **ema_kw)
     if carried_opt is not None:
         if carried_opt["m"].numel() != opt.m.numel():
             raise RuntimeError(f"optimizer state of {cfg['trainer']['load_path']} has {carried_opt['m'].numel()} elements, "
@@ -66,6 +74,8 @@ def train(cfg: dict):
     for name, alg in (cfg.get("algorithms") or {}).items():
         if name == "gradient_clipping":
             clip = float(alg["clip_norm"])
+        elif name == "ema":
+            pass                                                   # handled above (fused into the optimiser kernel)
         elif name != "low_precision_layernorm":                    # LP-LayerNorm is the engine's native numerics
             print(f"Algorithm {name} not supported.")              # same message as the reference (train.py:87-88)
     seq, emb = text_encoder_embedding_format(cfg["model"]["text_encoder_name"])
@@ -95,9 +105,18 @@ def train(cfg: dict):
             torch.cuda.set_rng_state(ck["rng_cuda"].cpu())
         if rank == 0:
             print(json.dumps({"resumed_from": latest, "batch": start}), flush=True)
+    eval_every = parse_batches(cfg["trainer"].get("eval_interval", "0ba") or "0ba")
+    eval_loader = None
+    if eval_every and ds.get("eval"):
+        eval_loader = mdcfg.instantiate(ds["eval"], image_size=ds["image_size"], batch_size=ds["eval_batch_size"] // world,
+                                        cap_seq_size=seq, cap_emb_dim=emb, loop=False)
     t_last = time.time()
     for step, batch in zip(range(start, max_ba), loader):
         loss = trainer.train_step(batch)
+        if eval_loader is not None and (step + 1) % eval_every == 0:
+            ev = evaluate(model, eval_loader, world)
+            if rank == 0:
+                print(json.dumps({"batch": step + 1, "metrics/eval/loss": ev}), flush=True)
         if not torch.isfinite(loss):                               # NaNCatcher (callbacks.py:47-64)
             raise RuntimeError(f"Train loss contains a NaN at batch {step}")
         if rank == 0 and (step + 1) % log_every == 0:
@@ -113,6 +132,23 @@ def train(cfg: dict):
                         "loader": loader.state_dict() if hasattr(loader, "state_dict") else None}, tmp)
             os.replace(tmp, os.path.join(folder, "latest.pt"))      # never leave a truncated latest.pt behind
     return trainer
+
+
+@torch.no_grad()
+def evaluate(model, eval_loader, world: int) -> float:
+    """Composer's eval loop around LatentDiffusion.eval_forward / DistLoss (model.py:217-229, utils.py:598-614): the EDM loss
+    at eval_mask_ratio = 0 (every token kept) averaged over the eval batches of all ranks."""
+    was_training = model.training
+    model.eval()
+    metric = model.get_metrics(is_train=False)["loss"]
+    for batch in eval_loader:
+        model.update_metric(batch, model.eval_forward(batch), metric)
+    model.train(was_training)
+    tot = torch.stack([torch.as_tensor(metric.loss, dtype=torch.float32, device="cuda").reshape(()),
+                       torch.tensor(float(metric.batches), device="cuda")])
+    if world > 1:
+        dist.all_reduce(tot)                    # DistLoss: dist_reduce_fx = "sum" for both states
+    return float(tot[0] / tot[1].clamp(min=1))
 
 
 def main():
