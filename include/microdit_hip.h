@@ -172,6 +172,8 @@ int md_cast_rows_bf16(const void* x, int32_t x_dtype, void* y, int64_t rows, int
 int md_mean_tokens(const void* y, void* out, int64_t B, int64_t L, int64_t C, hipStream_t stream);     /* dit.py:484 */
 int md_mean_tokens_bwd(const void* dpool, float* dy, int64_t B, int64_t L, int64_t C, hipStream_t stream); /* dy += */
 int md_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream);
+/* zero-fill (fp32 gradient accumulators, scatter targets): hipMemsetAsync on the caller's stream */
+int md_fill_zero(void* p, int64_t bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- masking / MoE routing */
 /* utils.py:382-403 given the uniform noise: stable ascending rank.  keep_rows[b*len_keep + r] = b*T + token with rank r
@@ -233,6 +235,10 @@ int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------- probes (tests only) */
 int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);
 int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream);
+/* vmcnt ordering: per lane one cold 16-byte load (lanes spread over `cold_bytes`), four hot stores, s_waitcnt vmcnt(4);
+ * *stale_lanes += lanes whose load had NOT landed (0 = loads and stores retire the counter in issue order). */
+int md_debug_vmcnt_order_probe(const void* cold, int64_t cold_bytes, void* hot, uint32_t* stale_lanes, int32_t blocks,
+                               hipStream_t stream);
 
 #ifdef __cplusplus
 }

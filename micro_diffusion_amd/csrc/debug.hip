@@ -32,6 +32,28 @@ __global__ void mfma_probe_kernel(const bf16* A /*[32][16]*/, const bf16* B /*[1
         D[row * 32 + (l & 31)] = acc[r];
     }
 }
+// Does vmcnt retire LOADS and STORES of one wave in issue order?  Every lane issues a cold 16-byte load (one distinct
+// cache line per lane of a large buffer: an HBM miss), then NST hot 16-byte stores (the same few L2-resident lines), then
+// waits s_waitcnt vmcnt(4): with in-order retirement the load, the oldest operation, must have landed.  The destination
+// register is pre-set to a sentinel inside the same asm; a lane that still reads the sentinel proves that younger stores
+// retired (dropped the counter) ahead of the older load.  out[0] += number of such lanes.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__global__ __launch_bounds__(256) void vmcnt_order_probe_kernel(const u32x4* cold, int64_t cold_stride16, u32x4* hot, unsigned* out) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const u32x4* src = cold + gid * cold_stride16;
+    u32x4* dst = hot + (threadIdx.x & 63);
+    u32x4 v = {0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu};
+    const u32x4 st = {1u, 2u, 3u, 4u};
+    asm volatile("global_load_dwordx4 %0, %1, off\n\t"
+                 "global_store_dwordx4 %2, %3, off\n\tglobal_store_dwordx4 %2, %3, off offset:1024\n\t"
+                 "global_store_dwordx4 %2, %3, off offset:2048\n\tglobal_store_dwordx4 %2, %3, off offset:3072\n\t"
+                 "s_waitcnt vmcnt(4)\n\ts_nop 1"
+                 : "+v"(v) : "v"(src), "v"(dst), "v"(st) : "memory");
+    const bool stale = (v[0] == 0xdeadbeefu);          // sampled right after the counted wait ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... before everything is drained
+    const unsigned long long m = __ballot(stale);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned)__popcll(m));
+}
 }  // namespace
 
 extern "C" int md_abi_version(void) { return MD_ABI_VERSION; }
@@ -44,6 +66,18 @@ extern "C" int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStr
 
 extern "C" int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream) {
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)A, (const bf16*)B, D);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_debug_vmcnt_order_probe(const void* cold, int64_t cold_bytes, void* hot, uint32_t* stale_lanes, int32_t blocks,
+                                          hipStream_t stream) {
+    if (!cold || !hot || !stale_lanes || blocks <= 0) return MD_BAD_ARG;
+    const int64_t lanes = (int64_t)blocks * 256;
+    const int64_t stride16 = cold_bytes / 16 / lanes;                 // one private, far-apart 16-byte word per lane
+    if (stride16 < 8) return MD_BAD_ARG;
+    hipLaunchKernelGGL(vmcnt_order_probe_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4*)cold, stride16, (u32x4*)hot,
+                       stale_lanes);
     MD_LAUNCH_CHECK();
     return 0;
 }

@@ -322,3 +322,11 @@ extern "C" int md_add_bf16(const void* a, const void* b, void* y, int64_t n, hip
     MD_LAUNCH_CHECK();
     return 0;
 }
+
+// Zero-fill of an activation / accumulator region (the engine's only "initialise" operation: fp32 gradient accumulators, the
+// scatter target of the un-masking backward).  hipMemsetAsync on the caller's stream: capturable, no at::native fill kernels.
+extern "C" int md_fill_zero(void* p, int64_t bytes, hipStream_t stream) {
+    if (!p || bytes < 0) return MD_BAD_ARG;
+    if (bytes == 0) return 0;
+    return (int)hipMemsetAsync(p, 0, (size_t)bytes, stream);
+}

@@ -35,6 +35,50 @@ class Tape:
     pass
 
 
+class _Arena:
+    """Bump allocator over ONE device buffer.  With it the activations, gradients and scratch of a microbatch live at fixed
+    addresses and the step path makes no allocator calls (no caching-allocator bookkeeping per launch, no at::native fill
+    kernels; the launch sequence of a microbatch becomes capturable as a hipGraph).  The first pass through a new shape runs
+    in measuring mode — plain torch.empty, sizes recorded with the same mark / release discipline — and the buffer is then
+    allocated once at the measured peak."""
+    ALIGN = 256
+
+    def __init__(self, dev):
+        self.dev, self.buf, self.key = dev, None, None
+        self.top = self.peak = 0
+        self.measuring = True
+
+    def begin(self, key):
+        if key != self.key:
+            self.key, self.buf, self.measuring, self.peak = key, None, True, 0
+        self.top = 0
+
+    def end(self):
+        if self.measuring:
+            self.buf = torch.empty(self.peak + self.ALIGN, device=self.dev, dtype=torch.uint8)
+            self.measuring = False
+
+    def mark(self) -> int:
+        return self.top
+
+    def release(self, mark: int) -> None:
+        self.top = mark
+
+    def alloc(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        off = self.top
+        self.top = (off + nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.peak = max(self.peak, self.top)
+        if self.measuring:
+            return torch.empty(*shape, device=self.dev, dtype=dtype)
+        if self.top > self.buf.numel():
+            raise RuntimeError("activation arena overflow: the launch sequence changed without a change of the shape key")
+        return self.buf[off:off + nbytes].view(dtype).view(*shape)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -54,16 +98,26 @@ class DiTEngine:
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
         self.ws = torch.empty(128 << 20, device=self.dev, dtype=F32)  # 512 MiB split-K workspace
+        # Fixed-address activation memory (opt-in: the caller must run forward -> backward strictly in turn, as the Trainer
+        # does; two forwards in flight would share the tape arena).
+        self.use_arena = False
+        self._tape_arena, self._scratch_arena = _Arena(self.dev), _Arena(self.dev)
+        self._arena = None          # arena the next empty() / zeros() comes from (None = torch allocator)
+        self._posb = None
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
 
     def empty(self, *shape, dtype=BF16):
+        if self._arena is not None:
+            return self._arena.alloc(shape, dtype)
         return torch.empty(*shape, device=self.dev, dtype=dtype)
 
     def zeros(self, *shape, dtype=F32):
-        return torch.zeros(*shape, device=self.dev, dtype=dtype)
+        t = self.empty(*shape, dtype=dtype)
+        hip.check(self.L.md_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._st()), "md_fill_zero")
+        return t
 
     def _gemm(self, **kw):
         a = hip.GemmArgs()
@@ -488,7 +542,25 @@ class DiTEngine:
         assert T == cfg.tokens, "input resolution does not match the model's position table"
         Lc, Dc = y.shape[-2], y.shape[-1]
         assert x_img.dtype == F32 and x_img.is_contiguous() and y.is_contiguous() and y.dtype in (torch.float16, F32)
+        grad_pass = self.use_arena and torch.is_grad_enabled()
+        if grad_pass:
+            self._tape_arena.begin((B, H, W, Lc, Dc, float(mask_ratio), str(y.dtype)))
+            self._arena = self._tape_arena
+        try:
+            return self._forward(x_img, t_in, y, mask_ratio, mask_noise, in_scale, y_rowscale)
+        finally:
+            if grad_pass:
+                self._tape_arena.end()
+            self._arena = None
+
+    def _forward(self, x_img, t_in, y, mask_ratio, mask_noise, in_scale, y_rowscale) -> Tape:
+        cfg, L, st = self.cfg, self.L, self._st()
+        B = x_img.shape[0]
+        C, H, W, p = cfg.in_channels, x_img.shape[-2], x_img.shape[-1], cfg.patch_size
+        T, D, Dm = (H // p) * (W // p), cfg.dim, cfg.patch_mixer_dim
+        Lc, Dc = y.shape[-2], y.shape[-1]
         tp = Tape()
+        tp.arena = self._arena is not None
         tp.B, tp.T, tp.Lc, tp.H, tp.W = B, T, Lc, H, W
         # ---- patch embedding (+ pos), dit.py:479
         tp.patches = self.empty(B * T, cfg.patch_vec)
@@ -500,7 +572,7 @@ class DiTEngine:
         tp.tok = tok
         # ---- timestep embedding, dit.py:480
         tp.tfreq = self.empty(B, 512)
-        t_f = t_in.to(F32).expand(B).contiguous()
+        t_f = t_in if (t_in.dtype == F32 and t_in.numel() == B and t_in.is_contiguous()) else t_in.to(F32).expand(B).contiguous()
         hip.check(L.md_timestep_embed(t_f.data_ptr(), tp.tfreq.data_ptr(), B, 512, st), "timestep_embed")
         tp.t_pre = self.empty(B, D)
         tp.t_h = self.empty(B, D)
@@ -564,7 +636,9 @@ class DiTEngine:
         else:
             # Identity maps (patch_mixer_dim == dim, dit.py:389-392): x = tok + pos
             x = self.empty(B * T, D)
-            posb = pos.to(BF16).expand(B, T, D).contiguous()
+            if self._posb is None or self._posb.shape[0] != B:          # constant table: built once per batch size
+                self._posb = pos.to(BF16).expand(B, T, D).contiguous()
+            posb = self._posb
             hip.check(L.md_add_bf16(tok.data_ptr(), posb.data_ptr(), x.data_ptr(), B * T * D, st), "add")
             ym = y2
         tp.ym = ym
@@ -630,6 +704,26 @@ class DiTEngine:
         """dtok: bf16 [B*Tk, p*p*C] grad of the network output for the kept tokens.  Accumulates every parameter
         gradient into the fp32 grad buffers (self.G).  `on_segment(prefix)` is called as soon as every kernel that
         writes the gradients of the parameters under `prefix` has been enqueued (data-parallel bucket hand-off)."""
+        use = self.use_arena and getattr(tp, "arena", False)
+        if use:
+            self._scratch_arena.begin((tp.B, tp.T, tp.Tk, tp.Lc, tp.H, tp.W))
+            self._arena = self._scratch_arena
+        try:
+            self._backward(tp, dtok, on_segment)
+        finally:
+            if use:
+                self._scratch_arena.end()
+            self._arena = None
+
+    def _block_bwd_scoped(self, *a):
+        """One block's backward; its temporaries are released when it returns (bump-arena mark / release)."""
+        if self._arena is None:
+            return self._block_bwd(*a)
+        m = self._arena.mark()
+        self._block_bwd(*a)
+        self._arena.release(m)
+
+    def _backward(self, tp: Tape, dtok: torch.Tensor, on_segment=None) -> None:
         cfg, L, st = self.cfg, self.L, self._st()
         seg = on_segment if on_segment is not None else (lambda name: None)
         B, T, Tk, Lc = tp.B, tp.T, tp.Tk, tp.Lc
@@ -653,7 +747,7 @@ class DiTEngine:
         seg("final_layer")
         # ---- backbone
         for bp, bt in zip(reversed(self.backbone), reversed(tp.blocks)):
-            self._block_bwd(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc)
+            self._block_bwd_scoped(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc)
             seg(bp.name)
         # ---- mixer -> backbone projection
         if cfg.use_patch_mixer and cfg.has_maps:
@@ -667,14 +761,14 @@ class DiTEngine:
         Wd = dx.shape[1]
         # ---- un-mask: scatter kept-token grads back to all T positions (zeros elsewhere)
         if tp.keep_rows is not None:
-            dfull = torch.zeros(B * T, Wd, device=self.dev, dtype=BF16)
+            dfull = self.zeros(B * T, Wd, dtype=BF16)
             hip.check(L.md_scatter_rows(dx.data_ptr(), Wd, tp.keep_rows.data_ptr(), dfull.data_ptr(), Wd, B * Tk, Wd, st), "scatter")
             dx = dfull
         # ---- patch mixer
         has_maps = cfg.use_patch_mixer and cfg.has_maps
         dym_f32 = self.zeros(Mc, Dm) if has_maps else dy2_f32
         for bp, bt in zip(reversed(self.mixer), reversed(tp.mixer)):
-            self._block_bwd(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc)
+            self._block_bwd_scoped(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc)
             seg(bp.name)
         # ---- map_xin / patch embedding
         if has_maps:

@@ -207,6 +207,7 @@ _sig("md_cast_rows_bf16", P, I32, P, I64, I64, P, I64, P)
 _sig("md_mean_tokens", P, P, I64, I64, I64, P)
 _sig("md_mean_tokens_bwd", P, P, I64, I64, I64, P)
 _sig("md_add_bf16", P, P, P, I64, P)
+_sig("md_fill_zero", P, I64, P)
 _sig("md_get_mask", P, I64, I64, I64, P, P, P, P)
 _sig("md_gather_rows", P, I64, P, P, I64, I64, I64, P)
 _sig("md_scatter_rows", P, I64, P, P, I64, I64, I64, P)
@@ -224,6 +225,7 @@ _sig("md_sumsq_finish", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_debug_tr_probe", P, P, P)
 _sig("md_debug_mfma_probe", P, P, P, P)
+_sig("md_debug_vmcnt_order_probe", P, I64, P, P, I32, P)
 
 
 def _declare(l: ctypes.CDLL) -> None:

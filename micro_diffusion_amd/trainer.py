@@ -260,6 +260,9 @@ class Trainer:
         self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
         model.dit._on_segment = self.sync.on_segment
+        # the Trainer runs forward -> backward strictly in turn: activations may live in the engine's fixed-address arenas
+        model.dit._ensure_flat()
+        model.dit.engine.use_arena = True
         self.batches_seen = 0
         self.log = log
         self._win: List[tuple] = []

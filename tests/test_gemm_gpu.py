@@ -173,3 +173,21 @@ def test_gemm_many_tiles_short_k(hip, akc, bkc):
     raw = torch.einsum("erd,efd->erf", X.float(), W.float())
     assert (H2.float() - raw).abs().max() <= 2e-2 * raw.abs().max()
     assert (H.float() - torch.nn.functional.gelu(raw)).abs().max() <= 2e-2 * raw.abs().max()
+
+
+def test_vmcnt_retires_loads_and_stores_in_issue_order(hip):
+    """The persistent GEMM counts its vector-memory operations by hand (s_waitcnt vmcnt(N) against the DMA ring and the prefetched
+    epilogue operands).  Its counts are exact only if a wave's loads and stores retire the counter in issue order — what
+    LLVM's own waitcnt insertion assumes on gfx9.  Probe: per lane one cold load (its own cache line of a 1 GiB buffer), four
+    hot stores, s_waitcnt vmcnt(4); a lane whose load had not landed would prove out-of-order retirement."""
+    dev = "cuda"
+    cold = torch.empty(1 << 28, device=dev, dtype=torch.float32).normal_()         # 1 GiB, far larger than L2 + Infinity Cache
+    hot = torch.zeros(4096, device=dev, dtype=torch.float32)
+    stale = torch.zeros(1, device=dev, dtype=torch.int32)
+    flush = torch.empty(1 << 27, device=dev, dtype=torch.float32)
+    for rep in range(8):
+        flush.normal_()                                                              # evict `cold` from the caches between rounds
+        hip.check(hip.lib().md_debug_vmcnt_order_probe(cold.data_ptr(), cold.numel() * 4, hot.data_ptr(), stale.data_ptr(), 4096,
+                                                       hip.stream_ptr()), "probe")
+    torch.cuda.synchronize()
+    assert int(stale.item()) == 0, f"{int(stale.item())} lanes saw a store retire ahead of an older load"
