@@ -209,6 +209,13 @@ int md_edm_loss(const void* tok, const int32_t* keep_rows, const float* xn, cons
                 float* loss_per_sample, float* loss_mean, float* dtok, int64_t B, int64_t Tk, int32_t C, int32_t H, int32_t W,
                 int32_t p, float sigma_data, hipStream_t stream);
 
+/* Sampler (model.py:231-297): the arithmetic around each network evaluation of the Heun loop, fused; fp64 state, fp32
+ * preconditioning (model.py:144-179) and classifier-free-guidance combine (dit.py:542-550: F = [cond; uncond] halves). */
+int md_edm_sampler_input(const double* x, float* out, int64_t n, float sigma, float sigma_data, int32_t duplicate, hipStream_t stream);
+int md_edm_heun_update(const double* x_hat, const double* x_in, const float* F, double* d_cur, double* x_next, int64_t n, float cfg,
+                       int32_t has_uncond, double t_in, double t_hat, double t_next, float sigma_data, int32_t second,
+                       hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------- optimiser */
 /* Sum of squares of a gradient buffer (fp32, or bf16 when g_is_bf16), deterministic: workgroup b of a fixed grid writes
  * partials[b] (MD_SUMSQ_PARTIALS floats per call); md_sumsq_finish adds `count` partials (several calls' worth, e.g. one per

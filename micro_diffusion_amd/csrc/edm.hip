@@ -127,6 +127,50 @@ inline int egrid(int64_t work) {
     return (int)g;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sampler (model.py:231-297): the arithmetic around each network evaluation of the Heun loop as two fused kernels, with the
+// reference's precisions: fp64 sampler state, fp32 preconditioning (model.py:144-179) and fp32 classifier-free-guidance
+// combine (dit.py:542-550).
+//   sampler_input : net_in = float(c_in(sigma) * float(x)), written once, or twice when the batch is doubled for guidance
+//   heun_update   : F = Fu + cfg * (Fc - Fu);  D = c_skip * float(x_in) + c_out * F;  d = (x_in - D) / sigma;
+//                   first half-step : d_cur = d, x_next = x_hat + (t_next - t_hat) * d
+//                   second half-step: x_next = x_hat + (t_next - t_hat) * (0.5 d_cur + 0.5 d)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sampler_input_kernel(const double* x, float* out, int64_t n, float sigma, float sigma_data, int dup) {
+    const float c_in = 1.f / sqrtf(sigma_data * sigma_data + sigma * sigma);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = c_in * (float)x[i];
+        out[i] = v;
+        if (dup) out[n + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void heun_update_kernel(const double* x_hat, const double* x_in, const float* F, double* d_cur,
+                                                          double* x_next, int64_t n, float cfg, int has_uncond, double t_in, double t_hat,
+                                                          double t_next, float sigma_data, int second) {
+    const float sg = (float)t_in;
+    const float den = sg * sg + sigma_data * sigma_data;
+    const float c_skip = sigma_data * sigma_data / den;
+    const float c_out = sg * sigma_data / sqrtf(den);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double xi = x_in[i];
+        float f = F[i];
+        if (has_uncond) {
+            const float fu = F[n + i];
+            f = fu + cfg * (f - fu);
+        }
+        const double D = (double)(c_skip * (float)xi + c_out * f);
+        const double d = (xi - D) / t_in;
+        const double xh = x_hat[i];
+        if (!second) {
+            d_cur[i] = d;
+            x_next[i] = xh + (t_next - t_hat) * d;
+        } else {
+            x_next[i] = xh + (t_next - t_hat) * (0.5 * d_cur[i] + 0.5 * d);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int md_edm_prepare(const float* x0, const float* eps, const float* rnd, float* xn, float* sigma, float* cin,
@@ -172,6 +216,24 @@ extern "C" int md_edm_loss(const void* tok, const int32_t* keep_rows, const floa
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(edm_loss_kernel, dim3((unsigned)B), dim3(256), 0, st, (const bf16*)tok, keep_rows, xn, x0, sigma,
                        loss_per_sample, loss_mean, dtok, B, Tk, C, H, W, p, sigma_data);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_edm_sampler_input(const double* x, float* out, int64_t n, float sigma, float sigma_data, int32_t duplicate,
+                                    hipStream_t st) {
+    if (!x || !out || n <= 0) return MD_BAD_ARG;
+    hipLaunchKernelGGL(sampler_input_kernel, dim3(egrid(n)), dim3(256), 0, st, x, out, n, sigma, sigma_data, duplicate);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_edm_heun_update(const double* x_hat, const double* x_in, const float* F, double* d_cur, double* x_next, int64_t n,
+                                  float cfg, int32_t has_uncond, double t_in, double t_hat, double t_next, float sigma_data,
+                                  int32_t second, hipStream_t st) {
+    if (!x_hat || !x_in || !F || !d_cur || !x_next || n <= 0 || t_in <= 0) return MD_BAD_ARG;
+    hipLaunchKernelGGL(heun_update_kernel, dim3(egrid(n)), dim3(256), 0, st, x_hat, x_in, F, d_cur, x_next, n, cfg, has_uncond, t_in,
+                       t_hat, t_next, sigma_data, second);
     MD_LAUNCH_CHECK();
     return 0;
 }

@@ -220,6 +220,8 @@ _sig("md_patchify", P, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_timestep_embed", P, P, I64, I32, P)
 _sig("md_unpatchify", P, P, I64, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_edm_loss", P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I32, F32, P)
+_sig("md_edm_sampler_input", P, P, I64, F32, F32, I32, P)
+_sig("md_edm_heun_update", P, P, P, P, P, I64, F32, I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, F32, I32, P)
 _sig("md_sumsq", P, I32, I64, P, P)
 _sig("md_sumsq_finish", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)

@@ -162,9 +162,17 @@ class LatentDiffusion(nn.Module):
 
     # ---------------------------------------------------------------------------------------- sampling (inference glue)
     @torch.no_grad()
-    def edm_sampler_loop(self, x, y, steps: Optional[int] = None, cfg: float = 1.0, **kwargs):
-        """Heun 2nd-order EDM sampler, fp64 state (model.py:231-297)."""
+    def edm_sampler_loop(self, x, y, steps: Optional[int] = None, cfg: float = 1.0, fused: Optional[bool] = None, **kwargs):
+        """Heun 2nd-order EDM sampler, fp64 state (model.py:231-297).  `fused` (None = whenever possible) selects the loop whose
+        per-step arithmetic runs in two fused HIP kernels; False keeps the reference's tensor-op formulation (generic forward
+        functions, S_churn > 0)."""
         ec = self.edm_config
+        can_fuse = ec.S_churn == 0 and not kwargs and x.is_cuda
+        if fused is None:
+            fused = can_fuse
+        if fused:
+            assert can_fuse, "the fused sampler needs S_churn == 0 and no extra forward arguments"
+            return self._edm_sampler_fused(x, y, steps, cfg)
         fwd = partial(self.dit.forward, cfg=cfg) if cfg > 1.0 else self.dit.forward
         n = ec.num_steps if steps is None else steps
         idx = torch.arange(n, dtype=torch.float64, device=x.device)
@@ -185,6 +193,40 @@ class LatentDiffusion(nn.Module):
                 d_prime = (x_next - den) / t_next
                 x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
         return x_next.to(torch.float32)
+
+    @torch.no_grad()
+    def _edm_sampler_fused(self, x, y, steps: Optional[int], cfg: float):
+        """The same Heun loop (S_churn = 0, the reference's setting: x_hat = x_cur) with everything around the network evaluations in
+        two fused HIP kernels: md_edm_sampler_input (c_in scaling + guidance batch doubling) and md_edm_heun_update (guidance
+        combine + preconditioning + fp64 Euler / Heun update)."""
+        ec, L, st = self.edm_config, hip.lib(), torch.cuda.current_stream().cuda_stream
+        n = ec.num_steps if steps is None else steps
+        idx = torch.arange(n, dtype=torch.float64)
+        inv_rho = 1 / ec.rho
+        t_steps = (ec.sigma_max ** inv_rho + idx / (n - 1) * (ec.sigma_min ** inv_rho - ec.sigma_max ** inv_rho)) ** ec.rho
+        t_steps = torch.cat([t_steps, torch.zeros(1, dtype=torch.float64)]).tolist()
+        guided = cfg > 1.0
+        B, numel = x.shape[0], x.numel()
+        x_cur = (x.to(torch.float64) * t_steps[0]).contiguous()
+        x_nxt, d_cur = torch.empty_like(x_cur), torch.empty_like(x_cur)
+        net_in = torch.empty((2 * B if guided else B,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        y2 = torch.cat([y, torch.zeros_like(y)], 0) if guided else y
+
+        def network(xs, sigma):
+            hip.check(L.md_edm_sampler_input(xs.data_ptr(), net_in.data_ptr(), numel, float(sigma), ec.sigma_data, 1 if guided else 0, st),
+                      "md_edm_sampler_input")
+            t = torch.full((1,), float(np.log(np.float32(sigma)) / 4), device=x.device, dtype=torch.float32)
+            return self.dit.forward_without_cfg(net_in, t, y2, 0)["sample"].contiguous()
+        for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+            F = network(x_cur, t_cur)
+            hip.check(L.md_edm_heun_update(x_cur.data_ptr(), x_cur.data_ptr(), F.data_ptr(), d_cur.data_ptr(), x_nxt.data_ptr(), numel,
+                                           float(cfg), 1 if guided else 0, t_cur, t_cur, t_next, ec.sigma_data, 0, st), "md_edm_heun_update")
+            if i < n - 1:
+                F = network(x_nxt, t_next)
+                hip.check(L.md_edm_heun_update(x_cur.data_ptr(), x_nxt.data_ptr(), F.data_ptr(), d_cur.data_ptr(), x_nxt.data_ptr(), numel,
+                                               float(cfg), 1 if guided else 0, t_next, t_cur, t_next, ec.sigma_data, 1, st), "md_edm_heun_update")
+            x_cur, x_nxt = x_nxt, x_cur
+        return x_cur.to(torch.float32)
 
     @torch.no_grad()
     def generate(self, prompt: Optional[list] = None, tokenized_prompts=None, attention_mask=None, guidance_scale: float = 5.0,

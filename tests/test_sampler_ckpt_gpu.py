@@ -38,6 +38,22 @@ def test_edm_sampler_vs_oracle(hip, guidance):
     assert rel < 0.05, rel          # bf16 network inside a 7-evaluation Heun integration vs the fp32 oracle
 
 
+@pytest.mark.parametrize("guidance", [1.0, 3.0])
+def test_fused_sampler_equals_tensor_op_sampler(hip, guidance):
+    """md_edm_sampler_input + md_edm_heun_update (guidance combine, preconditioning, fp64 Euler / Heun update in two kernels)
+    against the reference's formulation of the same loop in torch tensor ops (model.py:231-297, 144-179; dit.py:542-550):
+    identical precisions, so the two agree to fp32 round-off of the network input."""
+    cfg = orc.tiny_config()
+    model = _model(cfg, orc.synth_state_dict(cfg, 43))
+    g = torch.Generator().manual_seed(10)
+    lat = torch.randn(3, 4, 32, 32, generator=g).cuda()
+    y = torch.randn(3, 1, 77, 1024, generator=g).cuda()
+    a = model.edm_sampler_loop(lat, y, steps=5, cfg=guidance, fused=True)
+    b = model.edm_sampler_loop(lat, y, steps=5, cfg=guidance, fused=False)
+    rel = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    assert rel < 1e-3, rel      # bf16 network: a 1-ulp fp32 difference of its input can flip bf16 roundings inside
+
+
 def test_checkpoint_round_trip_and_stage_handoff(hip, tmp_path):
     cfg = orc.tiny_config()
     m = _model(cfg, seed=3)
