@@ -34,145 +34,9 @@
 //
 // Replaces the implicit cuBLAS calls behind every large nn.Linear / einsum of the reference
 // (micro_diffusion/models/dit.py:84-89,131-142,224; utils.py:58-61,109-111,172-173,225-233) and their backward.
-#include "md_common.h"
-#include "gemm_common.h"
+#include "gemm_pp_common.h"
 
 namespace {
-
-constexpr int PT = 256;            // output tile rows / columns
-constexpr int HT = 16384;          // bytes of one half-tile
-constexpr int B_REGION = 65536;    // A slots live in [0, 64 KiB), B slots in [64 KiB, 128 KiB): slot(b, h) = b * 32768 + h * 16384
-constexpr int NUM_CU = 256;        // MI355X
-
-template <int KC>
-struct Frag;
-template <>
-struct Frag<1> {
-    bf16x8 v;
-    __device__ __forceinline__ bf16x8 get() const { return v; }
-};
-template <>
-struct Frag<0> {
-    bf16x4 lo, hi;
-    __device__ __forceinline__ bf16x8 get() const {
-        bf16x8 f;
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return f;
-    }
-};
-
-// Fragment reads are inline asm: hipcc puts a full vmcnt(0) in front of every LDS read it can see while an LDS-DMA is
-// pending.  Their destinations are "pinned" after the caller's lgkmcnt(0) (frag_pin: an empty asm that re-defines the
-// registers), so no copy of a destination can be scheduled before the data has landed.
-template <int KC, int OFF>
-__device__ __forceinline__ void frag_read(Frag<KC>& f, unsigned addr) {
-    static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds offset field is 16 bits");
-    if constexpr (KC) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(addr), "i"(OFF) : "memory");
-    } else {
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                     : "=&v"(f.lo), "=&v"(f.hi)
-                     : "v"(addr), "i"(OFF), "i"(OFF + 1024)
-                     : "memory");
-    }
-}
-template <int KC>
-__device__ __forceinline__ void frag_pin(Frag<KC>& f) {
-    if constexpr (KC) asm volatile("" : "+v"(f.v));
-    else asm volatile("" : "+v"(f.lo), "+v"(f.hi));
-}
-
-// Per-lane LDS byte addresses of the fragment reads (computed once).
-//  K-contiguous: ad[ks] (k-step 0..3); the row-fragment index i is an immediate (i * 4096).
-//  K-strided   : ad[i]  (row-fragment 0..1); the k-step is an immediate (ks * 4096).
-// row0 = first row (column) of this wave's 64- (A) or 32- (B) wide strip inside the 128-wide half-tile.
-template <int KC>
-__device__ __forceinline__ void frag_addrs(unsigned (&ad)[4], unsigned base, int row0, int lane) {
-    if constexpr (KC) {
-        const int r = row0 + (lane & 31);
-        ad[0] = base + r * 128 + ((((lane >> 5) ^ (r >> 1)) & 7) << 4);   // k-step ks: chunk (2 ks + hi) ^ s == (hi ^ s) ^ 2 ks,
-        ad[1] = ad[2] = ad[3] = 0;                                        // i.e. ad[0] ^ (ks << 5)
-    } else {
-        const int li = lane & 15;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int col = row0 + i * 32 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
-            const int kk = (lane >> 5) * 8 + (li >> 2);
-            const int pc = (col >> 3) ^ ((kk & 3) << 2);
-            ad[i] = base + kk * 256 + pc * 16 + ((col >> 2) & 1) * 8;
-        }
-        ad[2] = ad[3] = 0;
-    }
-}
-template <int KC, int SLOT, int I, int KS>
-__device__ __forceinline__ void frag_read_at(Frag<KC>& f, const unsigned (&ad)[4], int kx32) {
-    // kx32 = 32 hidden behind an asm so that ad[0] ^ (KS * 32) is recomputed at the read (one v_xor) instead of living in
-    // three more registers per operand for the whole kernel
-    if constexpr (KC) frag_read<KC, SLOT + I * 4096>(f, KS == 0 ? ad[0] : (ad[0] ^ (unsigned)(KS * kx32)));
-    else frag_read<KC, SLOT + KS * 4096>(f, ad[I]);
-}
-
-// Per-lane byte offsets (relative to the tile's base pointer) of the two 1 KiB DMA pieces this wave contributes to each
-// half-tile h of an operand whose tile starts at row r0 (rmax rows in total).
-template <int KC>
-__device__ __forceinline__ void stage_offsets(unsigned (&ofs)[2][2], int r0, int rmax, int ld, int wave, int lane) {
-    asm volatile("" : "+v"(lane));     // evaluated once per output tile: keep its lane-derived sub-terms out of the loop-invariant registers
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if constexpr (KC) {
-                const int row = (wave * 2 + j) * 8 + (lane >> 3);            // row inside the half-tile
-                const int c = (lane & 7) ^ ((row >> 1) & 7);                  // logical 16-byte chunk this lane fetches
-                int gr = r0 + h * 128 + row;
-                gr = (gr < rmax ? gr : rmax - 1) - r0;
-                ofs[h][j] = (unsigned)(gr * ld + c * 8) * 2u;
-            } else {
-                const int kk = (wave * 2 + j) * 4 + (lane >> 4);
-                const int c = (lane & 15) ^ ((kk & 3) << 2);
-                int gc = r0 + h * 128 + c * 8;
-                const int last = (rmax - 1) & ~7;
-                gc = (gc < last ? gc : last) - r0;
-                ofs[h][j] = (unsigned)(kk * ld + gc) * 2u;
-            }
-        }
-}
-
-__device__ __forceinline__ void stage_half(const char* base, const unsigned (&ofs)[2], unsigned char* slot, int wave) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + ofs[j]), (lds_void_t*)(slot + (wave * 2 + j) * 1024), 16, 0, 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Work list.  W = tiles x batch x ksplit items; XCD x (workgroups with blockIdx % 8 == x share an L2) owns a contiguous
-// range of item ids, and its workgroups take consecutive ids in every round, so the ~32 tiles an XCD works on at any
-// time form a (32 / group_n) x group_n block of the output that shares A row-panels and B column-panels in L2.
-// The plan is computed on the host (md_gemm_pp_launch) and passed by value.
-// ---------------------------------------------------------------------------------------------------------------------
-struct PPPlan {
-    int ntm, ntn, ntiles, total;   // tiles per problem; items in total
-    int nk;                        // k-tiles (64 deep) per item, even
-    int kspan;                     // elements of K per split
-    int group_n;                   // column-tiles per raster group
-    int M, N, ksplit;
-    int lda, ldb;
-};
-
-__device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
-    const unsigned y = (unsigned)item / (unsigned)w.ntiles;
-    const unsigned t = (unsigned)item - y * (unsigned)w.ntiles;
-    batch = (int)(y / (unsigned)w.ksplit);
-    split = (int)(y - (unsigned)batch * (unsigned)w.ksplit);
-    const unsigned per_group = (unsigned)(w.group_n * w.ntm);
-    const unsigned g = t / per_group, rem = t - g * per_group;
-    const int first_n = (int)g * w.group_n;
-    const int gn = (w.ntn - first_n) < w.group_n ? (w.ntn - first_n) : w.group_n;
-    const unsigned tm = rem / (unsigned)gn;
-    m0 = (int)tm * PT;
-    n0 = (first_n + (int)(rem - tm * (unsigned)gn)) * PT;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Epilogue of one 64 x 32 quadrant (2 row-fragments of 32 x 32) of one wave.
@@ -181,53 +45,12 @@ __device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, 
 // The epilogue kind is a template parameter (one kernel per kind): with the mode and the activation as run-time values
 // every one of the eight inlined copies carried all the branches (65 k instructions per kernel).
 // ---------------------------------------------------------------------------------------------------------------------
-enum {
-    PP_E_BF16 = 0,       // MD_EPI_STORE_BF16, no activation            (+ bias, + C2)
-    PP_E_BF16_GELU = 1,  // MD_EPI_STORE_BF16, GELU(erf)                (+ bias, + C2: the MoE fc1)
-    PP_E_RES = 2,        // MD_EPI_RESIDUAL                             (+ bias, + gate, + C2)
-    PP_E_DACT_GELU = 3,  // MD_EPI_DACT through GELU(erf)               (the MoE fc1 dgrad)
-    PP_E_F32 = 4         // MD_EPI_STORE_F32                            (+ bias; split-K slices)
-    // MD_EPI_ACCUM_F32 stays on the gemm.hip kernels: its operand (32 fp32 per lane and quadrant) does not fit beside the
-    // fragments, and without the one-phase-ahead prefetch each quadrant would drain the DMA ring.
-};
-
-struct EpiTile {
-    int m0, n0, batch, split;
-};
-
-__device__ __forceinline__ uint4 asm_load16(const void* ptr) {
-    uint4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-
 template <int EPI>
 __device__ __forceinline__ int epi_prefetch_count(const md_gemm_args& p) {
     if (EPI == PP_E_RES) return p.gate ? 6 : 4;
     if (EPI == PP_E_DACT_GELU) return 4;
     return 0;
 }
-
-// Lane geometry of the epilogue: rl / cl = row / column inside the 256 x 256 tile of element block (i = 0, pp = 0) of
-// quadrant (0, 0); block (IH, JH, i, pp) adds (IH * 128 + i * 32) rows and (JH * 128 + pp * 16) columns.
-struct EpiLane {
-    int lane, wrow, wcol;   // wrow = wr * 64, wcol = wc * 32: this wave's strip inside a 128-wide half (wave-uniform)
-    // rl / cl are recomputed from the lane id at every use (behind an asm, so they are not hoisted into loop-invariant
-    // registers): every VGPR that lives across the main loop is one the fragment / prefetch registers cannot have.
-    __device__ __forceinline__ void coords(int& rl, int& cl) const {
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        rl = wrow + (l & 31);
-        cl = wcol + (l >> 5) * 8;
-    }
-};
-
-// All epilogue addresses are  uniform 64-bit base of the tile (SGPRs)  +  32-bit per-lane byte offset  (one VGPR each,
-// global_* saddr form): ptr + batch stride + m0 * ld + n0, and (row_in_tile * ld + col_in_tile) * element size.
-__device__ __forceinline__ const char* tile_base(const void* ptr, int64_t batch_off, const EpiTile& et, int64_t ld, int esize) {
-    return reinterpret_cast<const char*>(ptr) + (batch_off + (int64_t)et.m0 * ld + et.n0) * esize;
-}
-__device__ __forceinline__ unsigned lane_off(int r, int c, int ld, int esize) { return (unsigned)(r * ld + c) * (unsigned)esize; }
 
 // Operands of quadrant (IH, JH), requested one phase ahead.  Rows / columns are clamped into the matrix so every lane
 // issues every load (the counted waits rely on exact instruction counts).
@@ -265,22 +88,6 @@ __device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan
     }
 }
 
-__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
-    const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        f[2 * e] = __uint_as_float(w[e] << 16);
-        f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-    }
-}
-__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
-    U128 t;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
-    return t.u;
-}
-__device__ __forceinline__ float bf_round(float v) { return bf2f(f2bf(v)); }
-
 template <int EPI, int IH, int JH>
 __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et,
                                              const uint4 (&pre)[6], const EpiLane& el) {
@@ -292,6 +99,7 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
     const int ldc = (int)p.ldc;
     int rl, cl;
     el.coords(rl, cl);
+#ifndef PP_X_NO_EPI
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -330,10 +138,10 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
                     for (int e = 4; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 } else if (EPI == PP_E_RES) {
                     float rs[8];
-                    unpack8(pre[x], rs);
+                    unpack8(landed(pre[x]), rs);
                     if (p.gate) {
                         float g[8];
-                        unpack8(pre[4 + pp], g);
+                        unpack8(landed(pre[4 + pp]), g);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = rs[e] + g[e] * bf_round(v[e]);
                     } else {
@@ -342,14 +150,25 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
                     }
                 } else if (EPI == PP_E_DACT_GELU) {
                     float ax[8];
-                    unpack8(pre[x], ax);
+                    unpack8(landed(pre[x]), ax);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_f(ax[e]);
                     __builtin_amdgcn_sched_barrier(0);            // two batches of four: eight interleaved evaluations spill
 #pragma unroll
                     for (int e = 4; e < 8; ++e) v[e] *= dgelu_erf_f(ax[e]);
                 }
+#if defined(PP_X_NO_STORE)
+                { const uint4 pk = pack8(v); asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); }
+#elif defined(PP_X_ROWSTORE)
+                {   // timing only: full 128-byte lines, 8 rows per store instruction (wrong placement of the data)
+                    int l = el.lane;
+                    asm volatile("" : "+v"(l));
+                    const int rr = IH * 128 + el.wrow + (i * 2 + pp) * 8 + (l >> 3), cc = JH * 128 + (el.wcol & 64) + (l & 7) * 8;
+                    *reinterpret_cast<uint4*>(cbase + lane_off(rr, cc, ldc, 2)) = pack8(v);
+                }
+#else
                 if (ok) *reinterpret_cast<uint4*>(cbase + lane_off(r, c, ldc, 2)) = pack8(v);
+#endif
             } else {
                 if (ok) {
                     float* cp = reinterpret_cast<float*>(cbase + lane_off(r, c, ldc, 4));
@@ -358,13 +177,13 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
                 }
             }
         }
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 }
 
-#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 template <int AKC, int BKC, int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPlan w) {
@@ -385,6 +204,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         w_count = j < cnt ? (int)((unsigned)(cnt - j + w_stride - 1) / (unsigned)w_stride) : 0;
     }
     if (w_count == 0) return;
+    // Optional timeline (md_gemm_args.timeline, scripts/gemm_pp_timeline.py): 16 int64 per workgroup —
+    // [0] clock at entry  [1] wall clock at entry  [2] first k-tile landed  [3 + n] tile n's k-loop done (n < 8)
+    // [11] clock at exit  [12] wall clock at exit  [13] XCC_ID << 32 | HW_ID
+    long long* const tl = p.timeline ? static_cast<long long*>(p.timeline) + (size_t)blockIdx.x * 16 : nullptr;
+    if (tl && tid == 0) { tl[0] = clock64(); tl[1] = wall_clock64(); }
     const int half_iters = w_count * (w.nk >> 1);  // loop iterations: two k-tiles each
 
     // ---- per-lane constants
@@ -459,6 +283,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     PP_STAGE(0, 1); PP_STAGE(1, 1);
     PP_VMCNT(8);                                   // A0, B0 of k-tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
+    if (tl && tid == 0) tl[2] = clock64();
     // Group 1 runs one barrier behind group 0: two barriers per phase (load | compute) enforce strict alternation of the
     // groups' MFMA halves.  (A one-barrier-per-phase variant — group 0 passing it before its load half, group 1 between its
     // load and compute halves, so that no wave idles when its partner's half is the longer one — was correct and 5-10 %
@@ -594,12 +419,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         }
         PP_COMPUTE(2, fb0, PP_PIN_NONE());
         c_kt += 2;
-        if (last_pair) { c_kt = 0; ++c_n; epi_pending = true; }
+        if (last_pair) {
+            if (tl && tid == 0 && c_n < 8) tl[3 + c_n] = clock64();
+            c_kt = 0; ++c_n; epi_pending = true;
+        }
     }
     // ---- drain: the last tile's accumulators
     if (wr == 0) __builtin_amdgcn_s_barrier();     // pairs with group 1's extra barrier at the start
-    PP_VMCNT(0);
-    if (has_ops) { /* quadrant (0, 0)'s operands were requested in the last phase 8 */ }
+    PP_VMCNT(0);                                   // quadrant (0, 0)'s operands were requested in the last phase 8
+   
     epi_quadrant<EPI, 0, 0>(p, w, acc[0], et, pre, el);
     if (has_ops) { epi_prefetch<EPI, 0, 1>(p, w, et, pre, el); PP_VMCNT(0); }
     epi_quadrant<EPI, 0, 1>(p, w, acc[1], et, pre, el);
@@ -607,19 +435,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     epi_quadrant<EPI, 1, 1>(p, w, acc[3], et, pre, el);
     if (has_ops) { epi_prefetch<EPI, 1, 0>(p, w, et, pre, el); PP_VMCNT(0); }
     epi_quadrant<EPI, 1, 0>(p, w, acc[2], et, pre, el);
+    if (tl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store drain
+        if (tid == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tl[11] = clock64();
+            tl[12] = wall_clock64();
+            tl[13] = ((long long)xcc << 32) | hw;
+        }
+    }
 }
 
 }  // namespace
-
-static int pp_epi_kind(const md_gemm_args* a) {
-    switch (a->mode) {
-        case MD_EPI_STORE_BF16: return a->act == MD_ACT_NONE ? PP_E_BF16 : a->act == MD_ACT_GELU_ERF ? PP_E_BF16_GELU : -1;
-        case MD_EPI_RESIDUAL: return PP_E_RES;
-        case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? PP_E_DACT_GELU : -1;
-        case MD_EPI_STORE_F32: return PP_E_F32;
-        default: return -1;
-    }
-}
 
 // Layout x epilogue combinations that are instantiated = the ones the MicroDiT engine launches at sizes that fill the chip:
 //   NT (activations x torch weights): bf16, residual, dact(gelu)   NN (dgrads, MoE experts): bf16, bf16+gelu, residual, f32
@@ -632,7 +461,7 @@ static bool pp_instantiated(int akc, int bkc, int epi) {
 }
 
 bool md_gemm_pp_eligible(const md_gemm_args* a) {
-    const int epi = pp_epi_kind(a);
+    const int epi = md_gemm_pp_epi_kind(a);
     if (epi < 0 || !pp_instantiated(a->a_kcontig, a->b_kcontig, epi)) return false;
     if (a->K % a->ksplit) return false;
     const int64_t kspan = a->K / a->ksplit;
@@ -646,20 +475,10 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
 
 int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
     PPPlan w;
-    w.ntm = (int)((a->M + PT - 1) / PT);
-    w.ntn = (int)((a->N + PT - 1) / PT);
-    w.ntiles = w.ntm * w.ntn;
-    const int64_t total = (int64_t)w.ntiles * a->batch * a->ksplit;
-    if (total > (1 << 30)) return MD_BAD_ARG;
-    w.total = (int)total;
-    w.kspan = (int)(a->K / a->ksplit);
-    w.nk = w.kspan / BKT;
-    w.group_n = a->raster_group_n > 0 ? a->raster_group_n : 1;
-    w.M = (int)a->M; w.N = (int)a->N; w.ksplit = a->ksplit;
-    w.lda = (int)a->lda; w.ldb = (int)a->ldb;
-    const unsigned G = (unsigned)(total < NUM_CU ? total : NUM_CU);
+    if (!md_gemm_pp_plan(a, &w)) return MD_BAD_ARG;
+    const unsigned G = (unsigned)(w.total < NUM_CU ? w.total : NUM_CU);
     const dim3 grid(G, 1, 1), block(512);
-    const int epi = pp_epi_kind(a);
+    const int epi = md_gemm_pp_epi_kind(a);
 #define PP_LAUNCH(AK, BK, E) hipLaunchKernelGGL((gemm_bf16_pp_kernel<AK, BK, E>), grid, block, 0, stream, *a, w)
 #ifdef PP_EXPERIMENT_ONE   // compile-time experiments: a single instantiation
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<PP_EXPERIMENT_ONE>), grid, block, 0, stream, *a, w);

@@ -1,0 +1,242 @@
+// Device helpers shared by the two persistent GEMM kernels (gemm_pp.hip: whole-tile schedule; the half-by-half experiment under scripts/experiments:
+// schedule): fragment types and LDS reads, DMA staging offsets, the host-computed work plan, epilogue address helpers.
+#pragma once
+#include "md_common.h"
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PT = 256;            // output tile rows / columns
+constexpr int HT = 16384;          // bytes of one half-tile
+constexpr int B_REGION = 65536;    // A slots live in [0, 64 KiB), B slots in [64 KiB, 128 KiB): slot(b, h) = b * 32768 + h * 16384
+constexpr int NUM_CU = 256;        // MI355X
+
+template <int KC>
+struct Frag;
+template <>
+struct Frag<1> {
+    bf16x8 v;
+    __device__ __forceinline__ bf16x8 get() const { return v; }
+};
+template <>
+struct Frag<0> {
+    bf16x4 lo, hi;
+    __device__ __forceinline__ bf16x8 get() const {
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+};
+
+// Fragment reads are inline asm: hipcc puts a full vmcnt(0) in front of every LDS read it can see while an LDS-DMA is
+// pending.  Their destinations are "pinned" after the caller's lgkmcnt(0) (frag_pin: an empty asm that re-defines the
+// registers), so no copy of a destination can be scheduled before the data has landed.
+template <int KC, int OFF>
+__device__ __forceinline__ void frag_read(Frag<KC>& f, unsigned addr) {
+    static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds offset field is 16 bits");
+    if constexpr (KC) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(addr), "i"(OFF) : "memory");
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(f.lo), "=&v"(f.hi)
+                     : "v"(addr), "i"(OFF), "i"(OFF + 1024)
+                     : "memory");
+    }
+}
+template <int KC>
+__device__ __forceinline__ void frag_pin(Frag<KC>& f) {
+    if constexpr (KC) asm volatile("" : "+v"(f.v));
+    else asm volatile("" : "+v"(f.lo), "+v"(f.hi));
+}
+
+// Per-lane LDS byte addresses of the fragment reads (computed once).
+//  K-contiguous: ad[ks] (k-step 0..3); the row-fragment index i is an immediate (i * 4096).
+//  K-strided   : ad[i]  (row-fragment 0..1); the k-step is an immediate (ks * 4096).
+// row0 = first row (column) of this wave's 64- (A) or 32- (B) wide strip inside the 128-wide half-tile.
+template <int KC>
+__device__ __forceinline__ void frag_addrs(unsigned (&ad)[4], unsigned base, int row0, int lane) {
+    if constexpr (KC) {
+        const int r = row0 + (lane & 31);
+        ad[0] = base + r * 128 + ((((lane >> 5) ^ (r >> 1)) & 7) << 4);   // k-step ks: chunk (2 ks + hi) ^ s == (hi ^ s) ^ 2 ks,
+        ad[1] = ad[2] = ad[3] = 0;                                        // i.e. ad[0] ^ (ks << 5)
+    } else {
+        const int li = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = row0 + i * 32 + ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+            const int kk = (lane >> 5) * 8 + (li >> 2);
+            const int pc = (col >> 3) ^ ((kk & 3) << 2);
+            ad[i] = base + kk * 256 + pc * 16 + ((col >> 2) & 1) * 8;
+        }
+        ad[2] = ad[3] = 0;
+    }
+}
+template <int KC, int SLOT, int I, int KS>
+__device__ __forceinline__ void frag_read_at(Frag<KC>& f, const unsigned (&ad)[4], int kx32) {
+    // kx32 = 32 hidden behind an asm so that ad[0] ^ (KS * 32) is recomputed at the read (one v_xor) instead of living in
+    // three more registers per operand for the whole kernel
+    if constexpr (KC) frag_read<KC, SLOT + I * 4096>(f, KS == 0 ? ad[0] : (ad[0] ^ (unsigned)(KS * kx32)));
+    else frag_read<KC, SLOT + KS * 4096>(f, ad[I]);
+}
+
+// Per-lane byte offsets (relative to the tile's base pointer) of the two 1 KiB DMA pieces this wave contributes to each
+// half-tile h of an operand whose tile starts at row r0 (rmax rows in total).
+template <int KC>
+__device__ __forceinline__ void stage_offsets(unsigned (&ofs)[2][2], int r0, int rmax, int ld, int wave, int lane) {
+    asm volatile("" : "+v"(lane));     // evaluated once per output tile: keep its lane-derived sub-terms out of the loop-invariant registers
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (KC) {
+                const int row = (wave * 2 + j) * 8 + (lane >> 3);            // row inside the half-tile
+                const int c = (lane & 7) ^ ((row >> 1) & 7);                  // logical 16-byte chunk this lane fetches
+                int gr = r0 + h * 128 + row;
+                gr = (gr < rmax ? gr : rmax - 1) - r0;
+                ofs[h][j] = (unsigned)(gr * ld + c * 8) * 2u;
+            } else {
+                const int kk = (wave * 2 + j) * 4 + (lane >> 4);
+                const int c = (lane & 15) ^ ((kk & 3) << 2);
+                int gc = r0 + h * 128 + c * 8;
+                const int last = (rmax - 1) & ~7;
+                gc = (gc < last ? gc : last) - r0;
+                ofs[h][j] = (unsigned)(kk * ld + gc) * 2u;
+            }
+        }
+}
+
+__device__ __forceinline__ void stage_half(const char* base, const unsigned (&ofs)[2], unsigned char* slot, int wave) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + ofs[j]), (lds_void_t*)(slot + (wave * 2 + j) * 1024), 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Work list.  W = tiles x batch x ksplit items; XCD x (workgroups with blockIdx % 8 == x share an L2) owns a contiguous
+// range of item ids, and its workgroups take consecutive ids in every round, so the ~32 tiles an XCD works on at any
+// time form a (32 / group_n) x group_n block of the output that shares A row-panels and B column-panels in L2.
+// The plan is computed on the host (md_gemm_pp_launch) and passed by value.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PPPlan {
+    int ntm, ntn, ntiles, total;   // tiles per problem; items in total
+    int nk;                        // k-tiles (64 deep) per item, even
+    int kspan;                     // elements of K per split
+    int group_n;                   // column-tiles per raster group
+    int M, N, ksplit;
+    int lda, ldb;
+};
+
+__device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
+    const unsigned y = (unsigned)item / (unsigned)w.ntiles;
+    const unsigned t = (unsigned)item - y * (unsigned)w.ntiles;
+    batch = (int)(y / (unsigned)w.ksplit);
+    split = (int)(y - (unsigned)batch * (unsigned)w.ksplit);
+    const unsigned per_group = (unsigned)(w.group_n * w.ntm);
+    const unsigned g = t / per_group, rem = t - g * per_group;
+    const int first_n = (int)g * w.group_n;
+    const int gn = (w.ntn - first_n) < w.group_n ? (w.ntn - first_n) : w.group_n;
+    const unsigned tm = rem / (unsigned)gn;
+    m0 = (int)tm * PT;
+    n0 = (first_n + (int)(rem - tm * (unsigned)gn)) * PT;
+}
+
+enum {
+    PP_E_BF16 = 0,       // MD_EPI_STORE_BF16, no activation            (+ bias, + C2)
+    PP_E_BF16_GELU = 1,  // MD_EPI_STORE_BF16, GELU(erf)                (+ bias, + C2: the MoE fc1)
+    PP_E_RES = 2,        // MD_EPI_RESIDUAL                             (+ bias, + gate, + C2)
+    PP_E_DACT_GELU = 3,  // MD_EPI_DACT through GELU(erf)               (the MoE fc1 dgrad)
+    PP_E_F32 = 4         // MD_EPI_STORE_F32                            (+ bias; split-K slices)
+    // MD_EPI_ACCUM_F32 stays on the gemm.hip kernels: its operand (32 fp32 per lane and quadrant) does not fit beside the
+    // fragments, and without the one-phase-ahead prefetch each quadrant would drain the DMA ring.
+};
+
+struct EpiTile {
+    int m0, n0, batch, split;
+};
+
+__device__ __forceinline__ uint4 asm_load16(const void* ptr) {
+    uint4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+// A register filled by asm_load16 is valid only past the s_waitcnt that covers the load.  Epilogues read such a register
+// through landed(): an asm volatile cannot move above the (asm volatile) wait that precedes it in program order, and every use
+// of the value depends on its output — so no use can be scheduled in front of the wait.
+__device__ __forceinline__ uint4 landed(const uint4& v) {
+    uint4 t = v;
+    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+    return t;
+}
+
+// Lane geometry of the epilogue: rl / cl = row / column inside the 256 x 256 tile of element block (i = 0, pp = 0) of
+// quadrant (0, 0); block (IH, JH, i, pp) adds (IH * 128 + i * 32) rows and (JH * 128 + pp * 16) columns.
+struct EpiLane {
+    int lane, wrow, wcol;   // wrow = wr * 64, wcol = wc * 32: this wave's strip inside a 128-wide half (wave-uniform)
+    // rl / cl are recomputed from the lane id at every use (behind an asm, so they are not hoisted into loop-invariant
+    // registers): every VGPR that lives across the main loop is one the fragment / prefetch registers cannot have.
+    __device__ __forceinline__ void coords(int& rl, int& cl) const {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        rl = wrow + (l & 31);
+        cl = wcol + (l >> 5) * 8;
+    }
+};
+
+// All epilogue addresses are  uniform 64-bit base of the tile (SGPRs)  +  32-bit per-lane byte offset  (one VGPR each,
+// global_* saddr form): ptr + batch stride + m0 * ld + n0, and (row_in_tile * ld + col_in_tile) * element size.
+__device__ __forceinline__ const char* tile_base(const void* ptr, int64_t batch_off, const EpiTile& et, int64_t ld, int esize) {
+    return reinterpret_cast<const char*>(ptr) + (batch_off + (int64_t)et.m0 * ld + et.n0) * esize;
+}
+__device__ __forceinline__ unsigned lane_off(int r, int c, int ld, int esize) { return (unsigned)(r * ld + c) * (unsigned)esize; }
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(w[e] << 16);
+        f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    U128 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
+    return t.u;
+}
+__device__ __forceinline__ float bf_round(float v) { return bf2f(f2bf(v)); }
+
+#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// ---- host side, shared by the launchers
+inline int md_gemm_pp_epi_kind(const md_gemm_args* a) {
+    switch (a->mode) {
+        case MD_EPI_STORE_BF16: return a->act == MD_ACT_NONE ? PP_E_BF16 : a->act == MD_ACT_GELU_ERF ? PP_E_BF16_GELU : -1;
+        case MD_EPI_RESIDUAL: return PP_E_RES;
+        case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? PP_E_DACT_GELU : -1;
+        case MD_EPI_STORE_F32: return PP_E_F32;
+        default: return -1;
+    }
+}
+
+
+inline bool md_gemm_pp_plan(const md_gemm_args* a, PPPlan* w) {
+    w->ntm = (int)((a->M + PT - 1) / PT);
+    w->ntn = (int)((a->N + PT - 1) / PT);
+    w->ntiles = w->ntm * w->ntn;
+    const int64_t total = (int64_t)w->ntiles * a->batch * a->ksplit;
+    if (total > (1 << 30)) return false;
+    w->total = (int)total;
+    w->kspan = (int)(a->K / a->ksplit);
+    w->nk = w->kspan / BKT;
+    w->group_n = a->raster_group_n > 0 ? a->raster_group_n : 1;
+    w->M = (int)a->M;
+    w->N = (int)a->N;
+    w->ksplit = a->ksplit;
+    w->lda = (int)a->lda;
+    w->ldb = (int)a->ldb;
+    return true;
+}
+
+}  // namespace
