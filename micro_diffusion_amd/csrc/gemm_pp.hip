@@ -52,136 +52,156 @@ __device__ __forceinline__ int epi_prefetch_count(const md_gemm_args& p) {
     return 0;
 }
 
-// Operands of quadrant (IH, JH), requested one phase ahead.  Rows / columns are clamped into the matrix so every lane
-// issues every load (the counted waits rely on exact instruction counts).
+// Operands of quadrant (IH, JH), requested one phase ahead.  ONE request site per call site of the kernel (no fast / general
+// split here: see asm_load16); rows / columns are clamped into the matrix so every lane issues every load (the counted
+// waits rely on exact instruction counts) -- on interior tiles the clamps are no-ops.
 //   residual: pre[i * 2 + pp]; gate: pre[4 + pp] (rows_per_sample is a multiple of 64, so the 64 rows of a quadrant share one
 //   gate row); activation input: pre[i * 2 + pp].
 template <int EPI, int IH, int JH>
-__device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan& w, const EpiTile& et, uint4 (&pre)[6],
+__device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan& w, const EpiTile& et, u32x4 (&pre)[6],
                                              const EpiLane& el) {
+    const unsigned ld = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
     const int mlast = w.M - 1 - et.m0;                               // last valid row / first column of the last chunk, tile-relative
     const int nlast = ((w.N - 1) & ~7) - et.n0;
     int rl, cl;
     el.coords(rl, cl);
-    const char* base = EPI == PP_E_RES ? tile_base(p.res, 0, et, p.ldr, 2) : tile_base(p.aux, (int64_t)et.batch * p.sAux, et, p.ldaux, 2);
-    const int ld = EPI == PP_E_RES ? (int)p.ldr : (int)p.ldaux;
+    unsigned roff[2], coff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = rl + IH * 128 + i * 32;
+        roff[i] = (unsigned)(r < mlast ? r : mlast) * ld;
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int c = cl + JH * 128 + pp * 16;
+        coff[pp] = (unsigned)(c < nlast ? c : nlast);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            int r = rl + IH * 128 + i * 32, c = cl + JH * 128 + pp * 16;
-            r = r < mlast ? r : mlast;
-            c = c < nlast ? c : nlast;
-            pre[i * 2 + pp] = asm_load16(base + lane_off(r, c, ld, 2));
-        }
+        for (int pp = 0; pp < 2; ++pp) asm_load16(pre[i * 2 + pp], et.opbase + (roff[i] + coff[pp]) * 2u);
     if (EPI == PP_E_RES && p.gate) {
         int r0 = et.m0 + IH * 128 + el.wrow;                          // wave-uniform: the quadrant's first row
         r0 = r0 < w.M - 1 ? r0 : w.M - 1;
-        const char* g = reinterpret_cast<const char*>(p.gate) +
-                        ((int64_t)((unsigned)r0 / (unsigned)p.rows_per_sample) * p.ldg + et.n0) * 2;
+        const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
+        const char* g = et.gbase + (size_t)(srow * (unsigned)p.ldg) * 2;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            int c = cl + JH * 128 + pp * 16;
-            c = c < nlast ? c : nlast;
-            pre[4 + pp] = asm_load16(g + (unsigned)c * 2u);
-        }
+        for (int pp = 0; pp < 2; ++pp) asm_load16(pre[4 + pp], g + coff[pp] * 2u);
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of one quadrant.  One wave issues at most one instruction every four cycles and the other wave group's MFMA
+// half of a phase is 256 cycles long, so the instruction count of this routine is what an epilogue phase costs.  The
+// first version (per 8-element block: predicate + branch, 64-bit address arithmetic from the kernel arguments, four fp32
+// lane swaps, software re-interleave after the conversion: ~250 executed instructions per quadrant) made the phase 4-5x
+// longer than a plain one (tile time 25.6 -> 32.7 us at K = 1024).  Now: tile base pointers formed once per tile
+// (epi_open), one 32-bit lane offset per quadrant, conversion to bf16 BEFORE the half-wave swap (2 swaps of packed pairs
+// instead of 4 of fp32), fp32 outputs stored straight from the accumulator layout (a lane owns 4 consecutive columns =
+// 16 bytes), operands of fused epilogues swapped INTO the accumulator layout where the arithmetic is per element,
+// erf-GELU on pairs with one transcendental (md_common.h), accumulators cleared by the next MFMA (C = 0).
+// ---------------------------------------------------------------------------------------------------------------------
 template <int EPI, int IH, int JH>
-__device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et,
-                                             const uint4 (&pre)[6], const EpiLane& el) {
-    const float alpha = p.alpha;
-    const int mlim = w.M - et.m0, nlim = w.N - et.n0;
+__device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et, u32x4 (&pre)[6],
+                                             const EpiLane& el) {
     constexpr bool F32OUT = (EPI == PP_E_F32);
     constexpr int ES = F32OUT ? 4 : 2;
-    char* cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.batch * p.sC + (F32OUT ? (int64_t)et.split * p.sSplit : 0), et, p.ldc, ES));
-    const int ldc = (int)p.ldc;
-    int rl, cl;
-    el.coords(rl, cl);
-#ifndef PP_X_NO_EPI
+    constexpr int CW = F32OUT ? 4 : 8;                              // columns per store
+    const unsigned ldc = (unsigned)p.ldc;
+    int l = el.lane;
+    asm volatile("" : "+v"(l));                                   // recomputed per quadrant, not kept across the main loop
+    const int rl = el.wrow + (l & 31) + IH * 128;                 // row / first column inside the tile
+    const int cl = el.wcol + (l >> 5) * CW + JH * 128;
+    const int mlim = w.M - et.m0, nlim = w.N - et.n0;
+    const unsigned off0 = ((unsigned)rl * ldc + (unsigned)cl) * ES;
+    const unsigned rstep = 32u * ldc * ES;
+    const bool rok[2] = {rl < mlim, rl + 32 < mlim};
+    const float alpha = p.alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const unsigned off = i ? off0 + rstep : off0;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            const int r = rl + IH * 128 + i * 32, c = cl + JH * 128 + pp * 16;
-            const bool ok = r < mlim && c < nlim;
             const int x = i * 2 + pp;
+            const bool ok = rok[i] && cl + pp * 16 < nlim;          // N % 8 == 0: a store of 8 (4) columns is all inside or all outside
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // vdst = group 2 pp, src = group 2 pp + 1: lanes 0-31 end with [own g0 | upper's g0], lanes 32-63 with
-                // [lower's g1 | own g1]
-                const unsigned a = __float_as_uint(acc[i][8 * pp + e]);
-                const unsigned b = __float_as_uint(acc[i][8 * pp + 4 + e]);
-                const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                v[e] = __uint_as_float(sw[0]) * alpha;
-                v[4 + e] = __uint_as_float(sw[1]) * alpha;
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][8 * pp + e] * alpha;   // 4 v_pk_mul_f32 (a test for alpha == 1 costs more)
+            if (EPI != PP_E_DACT_GELU && p.bias) {                   // rare (MicroDiT's large layers have no bias): plain loads
+                const int cb = el.wcol + (l >> 5) * 4 + JH * 128 + pp * 16;   // accumulator layout: columns cb + e, cb + 8 + e
+                const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + cb;
+                if (cb < nlim) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bp);
+                    const float4 b1 = *reinterpret_cast<const float4*>(bp + 8);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
             }
-            if (EPI != PP_E_DACT_GELU && p.bias && ok) {
-                const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + c;
-                const float4 b0 = *reinterpret_cast<const float4*>(bp);
-                const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
-            if (!F32OUT) {
-                if (EPI != PP_E_DACT_GELU && p.C2 && ok) {
-                    char* c2 = const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2));
-                    *reinterpret_cast<uint4*>(c2 + lane_off(r, c, (int)p.ldc2, 2)) = pack8(v);
-                }
-                if (EPI == PP_E_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 4; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-                } else if (EPI == PP_E_RES) {
-                    float rs[8];
-                    unpack8(landed(pre[x]), rs);
-                    if (p.gate) {
-                        float g[8];
-                        unpack8(landed(pre[4 + pp]), g);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = rs[e] + g[e] * bf_round(v[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = rs[e] + bf_round(v[e]);
-                    }
-                } else if (EPI == PP_E_DACT_GELU) {
-                    float ax[8];
-                    unpack8(landed(pre[x]), ax);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_f(ax[e]);
-                    __builtin_amdgcn_sched_barrier(0);            // two batches of four: eight interleaved evaluations spill
-#pragma unroll
-                    for (int e = 4; e < 8; ++e) v[e] *= dgelu_erf_f(ax[e]);
-                }
-#if defined(PP_X_NO_STORE)
-                { const uint4 pk = pack8(v); asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); }
-#elif defined(PP_X_ROWSTORE)
-                {   // timing only: full 128-byte lines, 8 rows per store instruction (wrong placement of the data)
-                    int l = el.lane;
-                    asm volatile("" : "+v"(l));
-                    const int rr = IH * 128 + el.wrow + (i * 2 + pp) * 8 + (l >> 3), cc = JH * 128 + (el.wcol & 64) + (l & 7) * 8;
-                    *reinterpret_cast<uint4*>(cbase + lane_off(rr, cc, ldc, 2)) = pack8(v);
-                }
-#else
-                if (ok) *reinterpret_cast<uint4*>(cbase + lane_off(r, c, ldc, 2)) = pack8(v);
-#endif
+            if constexpr (F32OUT) {
+                float* cp = reinterpret_cast<float*>(et.cbase + pp * 16 * ES + off);
+                if (ok) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                if (rok[i] && cl + pp * 16 + 8 < nlim) *reinterpret_cast<float4*>(cp + 8) = make_float4(v[4], v[5], v[6], v[7]);
             } else {
-                if (ok) {
-                    float* cp = reinterpret_cast<float*>(cbase + lane_off(r, c, ldc, 4));
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                uint4 out;
+                const unsigned off2 = ((unsigned)(rl + i * 32) * (unsigned)p.ldc2 + (unsigned)cl) * 2u;
+                if constexpr (EPI == PP_E_BF16) {
+                    out = pack_swap8(v);
+                    if (et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = out;
+                } else if constexpr (EPI == PP_E_BF16_GELU) {
+                    if (et.c2base) {
+                        const uint4 lin = pack_swap8(v);
+                        if (ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = lin;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 g = gelu_erf_2(f32x2{v[e], v[e + 1]});
+                        v[e] = g.x;
+                        v[e + 1] = g.y;
+                    }
+                    out = pack_swap8(v);
+                } else if constexpr (EPI == PP_E_RES) {
+                    const uint4 lin = pack_swap8(v);                    // bf16(alpha * acc + bias): what nn.Linear returns under autocast
+                    if (et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = lin;
+                    const uint4 rsu = landed(pre[x]);
+                    const uint4 gu = p.gate ? landed(pre[4 + pp]) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
+                    const unsigned lw[4] = {lin.x, lin.y, lin.z, lin.w}, rw[4] = {rsu.x, rsu.y, rsu.z, rsu.w}, gw[4] = {gu.x, gu.y, gu.z, gu.w};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {                      // one packed pair at a time: few live registers
+                        const float y0 = __uint_as_float(lw[h] << 16), y1 = __uint_as_float(lw[h] & 0xffff0000u);
+                        const float r0 = __uint_as_float(rw[h] << 16), r1 = __uint_as_float(rw[h] & 0xffff0000u);
+                        const float g0 = __uint_as_float(gw[h] << 16), g1 = __uint_as_float(gw[h] & 0xffff0000u);
+                        ow[h] = cvt_pk_bf16(r0 + g0 * y0, r1 + g1 * y1);
+                    }
+                    out = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                } else {   // PP_E_DACT_GELU
+                    float ax[8];
+                    swap_unpack8(landed(pre[x]), ax);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 d = dgelu_erf_2(f32x2{ax[e], ax[e + 1]});
+                        v[e] *= d.x;
+                        v[e + 1] *= d.y;
+                    }
+                    out = pack_swap8(v);
                 }
+                if (ok) *reinterpret_cast<uint4*>(et.cbase + pp * 16 * ES + off) = out;
             }
         }
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    // (the accumulators are not cleared here: the first MFMA of the quadrant's next k-loop takes C = 0, PP_MFMA)
+}
+
+// Called (by every lane, all values wave-uniform) when a tile's k-loop ends: where its outputs and epilogue operands live.
+template <int EPI>
+__device__ __forceinline__ void epi_open(const md_gemm_args& p, const PPPlan& w, EpiTile& et) {
+    constexpr bool F32OUT = (EPI == PP_E_F32);
+    et.cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.batch * p.sC + (F32OUT ? (int64_t)et.split * p.sSplit : 0), et, p.ldc, F32OUT ? 4 : 2));
+    et.c2base = (!F32OUT && EPI != PP_E_DACT_GELU && p.C2) ? const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2)) : nullptr;
+    et.opbase = EPI == PP_E_RES        ? tile_base(p.res, 0, et, p.ldr, 2)
+                : EPI == PP_E_DACT_GELU ? tile_base(p.aux, (int64_t)et.batch * p.sAux, et, p.ldaux, 2)
+                                        : nullptr;
+    et.gbase = (EPI == PP_E_RES && p.gate) ? reinterpret_cast<const char*>(p.gate) + (size_t)et.n0 * 2 : nullptr;
 }
 
 
@@ -260,12 +280,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     int c_n = 0, c_kt = 0;
     bool epi_pending = false;
     int pf_after = 0;                              // DMA instructions issued after the pending operand prefetch
-    EpiTile et = {0, 0, 0, 0};
+    EpiTile et = {0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int npf = epi_prefetch_count<EPI>(p);
     const bool has_ops = npf > 0;
-    uint4 pre[6];
+    u32x4 pre[6];
 #pragma unroll
-    for (int x = 0; x < 6; ++x) pre[x] = make_uint4(0, 0, 0, 0);
+    for (int x = 0; x < 6; ++x) pre[x] = u32x4{0u, 0u, 0u, 0u};
 
     f32x16 acc[4][2];                              // quadrant q = ih * 2 + jh, row-fragment i
 #pragma unroll
@@ -310,9 +331,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
 #define PP_PIN_B(FB)                                                                                                    \
     do { frag_pin<BKC>(FB[0]); frag_pin<BKC>(FB[1]); frag_pin<BKC>(FB[2]); frag_pin<BKC>(FB[3]); } while (0)
     // D = B A^T: first operand = the B fragment (its 32 "rows" are output columns), second = the A fragment
-#define PP_MFMA(Q, FB)                                                                                                  \
+    // FRESH (wave-uniform): this quadrant was written out in the load half of this phase -- its first two MFMAs take C = 0
+    // (an inline constant) instead of 32 v_mov to clear the accumulators.
+#define PP_MFMA(Q, FB, FRESH)                                                                                           \
     do {                                                                                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+        {                                                                                                               \
+            const bf16x8 bq = FB[0].get();                                                                              \
+            if (FRESH) {                                                                                                \
+                acc[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[0][0].get(), zero16, 0, 0, 0);               \
+                acc[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[1][0].get(), zero16, 0, 0, 0);               \
+            } else {                                                                                                    \
+                acc[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[0][0].get(), acc[Q][0], 0, 0, 0);            \
+                acc[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[1][0].get(), acc[Q][1], 0, 0, 0);            \
+            }                                                                                                           \
+        }                                                                                                               \
+        _Pragma("unroll") for (int ks = 1; ks < 4; ++ks) {                                                              \
             const bf16x8 bq = FB[ks].get();                                                                             \
             acc[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[0][ks].get(), acc[Q][0], 0, 0, 0);               \
             acc[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, fa[1][ks].get(), acc[Q][1], 0, 0, 0);               \
@@ -323,14 +356,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     do {                                                                                                                \
         if (epi_pending) {                                                                                              \
             if (has_ops) { if (pf_after) PP_VMCNT(2); else PP_VMCNT(0); }                                               \
-            epi_quadrant<EPI, IH, JH>(p, w, acc[Q], et, pre, el);                                                     \
-            if (HAS_NEXT) { if (has_ops) { epi_prefetch<EPI, NIH, NJH>(p, w, et, pre, el); pf_after = 0; } }         \
+            epi_quadrant<EPI, IH, JH>(p, w, acc[Q], et, pre, el);                                                       \
+            if (HAS_NEXT) {                                                                                             \
+                if (has_ops) {                                                                                          \
+                    epi_prefetch<EPI, NIH, NJH>(p, w, et, pre, el);                                                     \
+                    pf_after = 0;                                                                                       \
+                }                                                                                                       \
+            }                                                                                                           \
             else epi_pending = false;                                                                                   \
         }                                                                                                               \
     } while (0)
     // RAW guard of the DMA ring: the half-tile issued 4 phases ago has landed (8 younger DMA instructions may be pending).
-    // In an epilogue phase with prefetched operands the operand wait at its top has already proven that (loads complete
-    // in order) and a count of 8 here would wait for the prefetch just issued.
+    // vmcnt also counts the epilogue stores, so in an epilogue phase this waits for more than it must; counts that allow for
+    // the stores (8 + stores per quadrant x quadrants written in the last four phases) were measured and LOST 3-7 % on the
+    // long-K shapes -- the extra uniform branches per phase cost more than the waits (profiles/r2_gemm_pp256_epilogue_v2.txt).
+    // In an epilogue phase with prefetched operands the operand wait at its top has already proven the landing (loads
+    // complete in order) and a count of 8 here would wait for the prefetch just issued.
 #define PP_RAW_WAIT(EPI_PHASE)                                                                                          \
     do {                                                                                                                \
         if (!((EPI_PHASE) && has_ops && epi_was)) {                                                                     \
@@ -339,14 +380,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         }                                                                                                               \
     } while (0)
 #define PP_PIN_NONE() do { } while (0)
-#define PP_COMPUTE(Q, FB, PINS)                                                                                         \
+#define PP_COMPUTE(Q, FB, PINS, FRESH)                                                                                       \
     do {                                                                                                                \
         __builtin_amdgcn_s_barrier();                                                                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
         PINS;                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
-        PP_MFMA(Q, FB);                                                                                                 \
+        PP_MFMA(Q, FB, FRESH);                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_barrier();                                                                                   \
@@ -364,44 +405,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         PP_READ_B(fb0, 0, 0); PP_READ_A(0, 0);
         PP_STAGE(2, 1); if (s_live) pf_after = 2;
         PP_RAW_WAIT(true);
-        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A());
+        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A(), epi_was);
         // phase 2: quadrant (0, 1) <- A0 B1
         epi_was = epi_pending;
         PP_EPI(0, 1, 1, 1, 1, true);
         PP_READ_B(fb1, 0, 1);
         { const bool live = s_live; PP_STAGE(3, 1); if (live) pf_after = 2; }
         PP_RAW_WAIT(true);
-        PP_COMPUTE(1, fb1, PP_PIN_B(fb1));
+        PP_COMPUTE(1, fb1, PP_PIN_B(fb1), epi_was);
         // phase 3: quadrant (1, 1) <- A1 B1
         epi_was = epi_pending;
         PP_EPI(1, 1, 3, 1, 0, true);
         PP_READ_A(0, 1);
         PP_STAGE(0, 0); if (s_live) pf_after = 2;
         PP_RAW_WAIT(true);
-        PP_COMPUTE(3, fb1, PP_PIN_A());
+        PP_COMPUTE(3, fb1, PP_PIN_A(), epi_was);
         // phase 4: quadrant (1, 0) <- A1 B0
         epi_was = epi_pending;
         PP_EPI(1, 0, 2, 0, 0, false);
         PP_STAGE(1, 0);
         PP_RAW_WAIT(true);
-        PP_COMPUTE(2, fb0, PP_PIN_NONE());
+        PP_COMPUTE(2, fb0, PP_PIN_NONE(), epi_was);
         // ================= k-tile in buffer 1 =================
         epi_was = false;
         PP_READ_B(fb0, 1, 0); PP_READ_A(1, 0);
         PP_STAGE(2, 0);
         PP_RAW_WAIT(false);
-        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A());
+        PP_COMPUTE(0, fb0, PP_PIN_B(fb0); PP_PIN_A(), false);
         PP_READ_B(fb1, 1, 1);
         PP_STAGE(3, 0);
         PP_RAW_WAIT(false);
-        PP_COMPUTE(1, fb1, PP_PIN_B(fb1));
+        PP_COMPUTE(1, fb1, PP_PIN_B(fb1), false);
         PP_READ_A(1, 1);
         PP_STAGE(0, 1);
         PP_RAW_WAIT(false);
-        PP_COMPUTE(3, fb1, PP_PIN_A());
+        PP_COMPUTE(3, fb1, PP_PIN_A(), false);
         // phase 8: on the last k-tile pair of an output tile, request the operands of the first epilogue quadrant
         if (last_pair) {
             work_decode(w, w_first + c_n * w_stride, et.m0, et.n0, et.batch, et.split);
+            epi_open<EPI>(p, w, et);
             if (has_ops) epi_prefetch<EPI, 0, 0>(p, w, et, pre, el);
         }
         {
@@ -417,7 +459,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
                 if (live) PP_VMCNT(8); else PP_VMCNT(0);
             }
         }
-        PP_COMPUTE(2, fb0, PP_PIN_NONE());
+        PP_COMPUTE(2, fb0, PP_PIN_NONE(), false);
         c_kt += 2;
         if (last_pair) {
             if (tl && tid == 0 && c_n < 8) tl[3 + c_n] = clock64();
@@ -428,13 +470,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     if (wr == 0) __builtin_amdgcn_s_barrier();     // pairs with group 1's extra barrier at the start
     PP_VMCNT(0);                                   // quadrant (0, 0)'s operands were requested in the last phase 8
    
-    epi_quadrant<EPI, 0, 0>(p, w, acc[0], et, pre, el);
-    if (has_ops) { epi_prefetch<EPI, 0, 1>(p, w, et, pre, el); PP_VMCNT(0); }
-    epi_quadrant<EPI, 0, 1>(p, w, acc[1], et, pre, el);
-    if (has_ops) { epi_prefetch<EPI, 1, 1>(p, w, et, pre, el); PP_VMCNT(0); }
-    epi_quadrant<EPI, 1, 1>(p, w, acc[3], et, pre, el);
-    if (has_ops) { epi_prefetch<EPI, 1, 0>(p, w, et, pre, el); PP_VMCNT(0); }
-    epi_quadrant<EPI, 1, 0>(p, w, acc[2], et, pre, el);
+#define PP_DRAIN_Q(IH, JH, Q) epi_quadrant<EPI, IH, JH>(p, w, acc[Q], et, pre, el)
+#define PP_DRAIN_PF(IH, JH)                                                                                             \
+    do {                                                                                                                \
+        if (has_ops) {                                                                                                  \
+            epi_prefetch<EPI, IH, JH>(p, w, et, pre, el);                                                               \
+            PP_VMCNT(0);                                                                                                \
+        }                                                                                                               \
+    } while (0)
+    PP_DRAIN_Q(0, 0, 0);
+    PP_DRAIN_PF(0, 1);
+    PP_DRAIN_Q(0, 1, 1);
+    PP_DRAIN_PF(1, 1);
+    PP_DRAIN_Q(1, 1, 3);
+    PP_DRAIN_PF(1, 0);
+    PP_DRAIN_Q(1, 0, 2);
     if (tl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store drain
         if (tid == 0) {
@@ -470,6 +520,8 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
     if (a->M >= (1 << 30) || a->N >= (1 << 30) || a->K >= (1 << 30)) return false;
     if (a->lda > (1 << 22) || a->ldb > (1 << 22)) return false;  // 32-bit per-lane DMA offsets
+    if (a->ldc > (1 << 20) || a->ldc2 > (1 << 20) || a->ldr > (1 << 20) || a->ldaux > (1 << 20) || a->ldg > (1 << 20))
+        return false;                                            // 32-bit per-lane epilogue offsets (256 rows x ld x 4 bytes)
     return true;
 }
 

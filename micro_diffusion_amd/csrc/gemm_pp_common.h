@@ -125,6 +125,7 @@ struct PPPlan {
     int group_n;                   // column-tiles per raster group
     int M, N, ksplit;
     int lda, ldb;
+    int rps_shift;                 // log2(rows_per_sample) when that is a power of two, else -1 (gated residual only)
 };
 
 __device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
@@ -153,21 +154,29 @@ enum {
 
 struct EpiTile {
     int m0, n0, batch, split;
+    // filled by epi_open() when the tile's k-loop finishes (all wave-uniform):
+    char* cbase;           // &C[batch, (split,) m0, n0]
+    char* c2base;          // &C2[batch, m0, n0] or nullptr
+    const char* opbase;    // &res[m0, n0] (RESIDUAL) / &aux[batch, m0, n0] (DACT)
+    const char* gbase;     // &gate[0, n0] or nullptr
 };
 
-__device__ __forceinline__ uint4 asm_load16(const void* ptr) {
-    uint4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
+// Epilogue operand loads are inline asm with hand-counted waits (hipcc would put a vmcnt(0) in front of their first use and
+// drain the DMA ring).  The compiler therefore does not know that the destination is not valid yet, and any register COPY
+// it places between the load and the wait would copy stale data.  What keeps copies out of that window:
+//  * ONE request routine per call site of the kernel (epi_prefetch has no fast / general split): with two sibling request
+//    sites merged by a phi, the two asm results were allocated to different physical registers and a v_mov followed the load
+//    directly -> NaNs.  scripts/check_pp_asm.py verifies on the built code that every request site of a kernel's main loop
+//    writes the same physical registers (tests/test_build_static.py runs it);
+//  * the consumer re-defines the registers in place (landed(): an empty asm volatile, which cannot move above the asm
+//    volatile wait that precedes it in program order) before their first use.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void asm_load16(u32x4& dst, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
 }
-
-// A register filled by asm_load16 is valid only past the s_waitcnt that covers the load.  Epilogues read such a register
-// through landed(): an asm volatile cannot move above the (asm volatile) wait that precedes it in program order, and every use
-// of the value depends on its output — so no use can be scheduled in front of the wait.
-__device__ __forceinline__ uint4 landed(const uint4& v) {
-    uint4 t = v;
-    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
-    return t;
+__device__ __forceinline__ uint4 landed(u32x4& v) {
+    asm volatile("" : "+v"(v));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // Lane geometry of the epilogue: rl / cl = row / column inside the 256 x 256 tile of element block (i = 0, pp = 0) of
@@ -207,7 +216,37 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 }
 __device__ __forceinline__ float bf_round(float v) { return bf2f(f2bf(v)); }
 
+// {lo, hi} -> packed bf16 pair (round to nearest even), one instruction; spelled out so that the pairing is the one the
+// epilogue wants (hipcc's own vectorisation of eight scalar conversions paired (0,2)(1,3) and re-shuffled afterwards).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// v_permlane32_swap: the upper half-wave of a and the lower half-wave of b change places.
+__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = sw[0];
+    b = sw[1];
+}
+// Eight fp32 in the accumulator ("pre-swap") layout -- v[0..3] = columns 4 hi + e of the block's first 8-column group,
+// v[4..7] = the same of its second group -- to one 16-byte row piece of 8 consecutive columns (16 pp + 8 hi ..).
+__device__ __forceinline__ uint4 pack_swap8(const float (&v)[8]) {
+    unsigned a0 = cvt_pk_bf16(v[0], v[1]), a1 = cvt_pk_bf16(v[2], v[3]);
+    unsigned b0 = cvt_pk_bf16(v[4], v[5]), b1 = cvt_pk_bf16(v[6], v[7]);
+    half_swap(a0, b0);
+    half_swap(a1, b1);
+    return make_uint4(a0, a1, b0, b1);
+}
+// The inverse for an operand that was loaded as a 16-byte row piece: back to the accumulator layout, as fp32.
+__device__ __forceinline__ void swap_unpack8(uint4 u, float (&f)[8]) {
+    half_swap(u.x, u.z);
+    half_swap(u.y, u.w);
+    unpack8(u, f);
+}
+
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
 
 // ---- host side, shared by the launchers
 inline int md_gemm_pp_epi_kind(const md_gemm_args* a) {
@@ -236,6 +275,11 @@ inline bool md_gemm_pp_plan(const md_gemm_args* a, PPPlan* w) {
     w->ksplit = a->ksplit;
     w->lda = (int)a->lda;
     w->ldb = (int)a->ldb;
+    w->rps_shift = -1;
+    if (a->rows_per_sample > 0 && (a->rows_per_sample & (a->rows_per_sample - 1)) == 0) {
+        w->rps_shift = 0;
+        while (((int64_t)1 << w->rps_shift) < a->rows_per_sample) ++w->rps_shift;
+    }
     return true;
 }
 

@@ -115,6 +115,39 @@ __device__ __forceinline__ float dgelu_erf_f(float x) {
     const float cdf = normal_cdf_f(x, e);
     return cdf + x * 0.3989422804014327f * e;
 }
+// The same two functions on PAIRS, for the fused GEMM epilogues (128 evaluations per lane and output tile; with the scalar
+// form above the MoE fc1 epilogue needed more VALU cycles than its k-loop needs MFMA cycles).  One transcendental instead
+// of two and packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32):
+//   Q(u) = Phi(-u) = exp(-u^2 / 2) * R(u),  R(u) = erfcx(u / sqrt 2) / 2 ~ degree-8 polynomial on [0, 6] (weighted minimax fit,
+//   scripts/fit_normal_tail.py: |Phi error| <= 4e-6, |GELU error| <= 1.6e-6 -- three orders below bf16 rounding);
+//   beyond |x| = 6 the argument is clamped (Q < 1e-9 there).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void normal_tail2(f32x2 x, f32x2& q, f32x2& e) {
+    const f32x2 a = {fminf(fabsf(x.x), 6.f), fminf(fabsf(x.y), 6.f)};
+    f32x2 p = 2.5696488483e-05f * a + -4.5856760922e-04f;
+    p = p * a + 3.5954925116e-03f;
+    p = p * a + -1.6710778400e-02f;
+    p = p * a + 5.3111584618e-02f;
+    p = p * a + -1.2762509357e-01f;
+    p = p * a + 2.4839277447e-01f;
+    p = p * a + -3.9874859017e-01f;
+    p = p * a + 4.9999610713e-01f;
+    const f32x2 t = (a * a) * -0.7213475204444817f;          // -u^2 / 2 * log2(e)
+    e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    q = p * e;
+}
+__device__ __forceinline__ f32x2 gelu_erf_2(f32x2 x) {
+    f32x2 q, e;
+    normal_tail2(x, q, e);
+    const f32x2 r = 1.f - q;
+    return x * f32x2{x.x < 0.f ? q.x : r.x, x.y < 0.f ? q.y : r.y};
+}
+__device__ __forceinline__ f32x2 dgelu_erf_2(f32x2 x) {
+    f32x2 q, e;
+    normal_tail2(x, q, e);
+    const f32x2 r = 1.f - q;
+    return f32x2{x.x < 0.f ? q.x : r.x, x.y < 0.f ? q.y : r.y} + (x * 0.3989422804014327f) * e;
+}
 __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
     float s = fast_rcp(1.f + __expf(-x));
