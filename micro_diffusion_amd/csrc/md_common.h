@@ -62,11 +62,21 @@ __device__ __forceinline__ void st_bf16x4(bf16* p, bf16x4 v) {
     *reinterpret_cast<uint2*>(p) = t.u;
 }
 
-// 64-lane butterfly reductions (every lane ends with the result).
+// 64-lane reductions (every lane ends with the result).  DPP row shifts + row broadcasts (6 VALU instructions with a DPP
+// modifier, then v_readlane of lane 63): the __shfl_xor butterfly compiles to six DEPENDENT ds_bpermute_b32 -- six LDS
+// round trips, ~600 cycles per reduction -- and the LayerNorm kernels do two or three reductions per 2 KB row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0x111, 0xf>(v);   // row_shr:1   (lanes without a source keep old = 0)
+    v += dpp_f<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_f<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_f<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_f<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

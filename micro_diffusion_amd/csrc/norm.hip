@@ -61,6 +61,27 @@ __device__ __forceinline__ void load_row(const md_ln_args& p, int64_t row, int l
     }
 }
 
+// Hot path (no pos table, no pre-norm activation): the 16-byte loads of a row, kept packed so that the NEXT row's loads can
+// be issued before the current row's reductions (one wave has two rows of loads in flight instead of one).
+template <int NCH>
+__device__ __forceinline__ void issue_row(const bf16* xr, int C, int lane, bf16x8 (&h)[NCH]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < C) h[j] = ld_bf16x8(xr + c);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[j][e] = (bf16)0.f;
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void unpack_row(const bf16x8 (&h)[NCH], float (&v)[NCH][8]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = bf2f(h[j][e]);
+}
+
 template <int NCH>
 __device__ __forceinline__ void load_cols_f32(const float* w, int C, int lane, float (&o)[NCH][8], float fill) {
 #pragma unroll
@@ -90,9 +111,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(md_ln_args p, int64_t rows_
     float wk[NCH][8];
     load_cols_f32<NCH>(reinterpret_cast<const float*>(p.w), (int)p.C, lane, wk, 1.f);
     const bool mod = p.scale != nullptr;
+    bf16x8 nxt[NCH];
+    if (!GENERIC && r0 < r1) issue_row<NCH>(reinterpret_cast<const bf16*>(p.x) + r0 * p.ldx, (int)p.C, lane, nxt);
     for (int64_t row = r0; row < r1; ++row) {
         float v[NCH][8], raw[1][8];
-        load_row<NCH, GENERIC, false>(p, row, lane, v, raw);
+        if (GENERIC) {
+            load_row<NCH, GENERIC, false>(p, row, lane, v, raw);
+        } else {
+            unpack_row<NCH>(nxt, v);
+            if (row + 1 < r1) issue_row<NCH>(reinterpret_cast<const bf16*>(p.x) + (row + 1) * p.ldx, (int)p.C, lane, nxt);
+        }
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
@@ -175,20 +203,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
             if (sc && c < p.C) wm[j][e] *= 1.f + bf2f(scv[e]);
         }
     }
+    bf16x8 nx[NCH], nz[NCH];
+    float nmean = 0.f, nrstd = 0.f;
+    if (r0 < r1) {
+        const int64_t row = smp * rps + r0;
+        if (!GENERIC) issue_row<NCH>(reinterpret_cast<const bf16*>(p.x) + row * p.ldx, (int)p.C, lane, nx);
+        issue_row<NCH>(reinterpret_cast<const bf16*>(b.dz) + row * b.lddz, (int)p.C, lane, nz);
+        nmean = reinterpret_cast<const float*>(p.mean)[row];
+        nrstd = reinterpret_cast<const float*>(p.rstd)[row];
+    }
     for (int64_t lr = r0; lr < r1; ++lr) {
         const int64_t row = smp * rps + lr;
         float v[NCH][8], raw[GENERIC ? NCH : 1][8];
-        load_row<NCH, GENERIC, GENERIC>(p, row, lane, v, raw);
-        const float mean = reinterpret_cast<const float*>(p.mean)[row];
-        const float rstd = reinterpret_cast<const float*>(p.rstd)[row];
-        const bf16* dzr = reinterpret_cast<const bf16*>(b.dz) + row * b.lddz;
+        if (GENERIC) load_row<NCH, GENERIC, GENERIC>(p, row, lane, v, raw);
+        else unpack_row<NCH>(nx, v);
+        const float mean = nmean, rstd = nrstd;
         float g[NCH][8];  // dL/dxhat
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane * 8 + j * 512;
             if (c < p.C) {
-                const bf16x8 dzv = ld_bf16x8(dzr + c);
+                const bf16x8 dzv = nz[j];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float dz = bf2f(dzv[e]);
@@ -205,6 +241,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[j][e] = 0.f;
             }
+        }
+        if (lr + 1 < r1) {    // the next row's loads fly during this row's reductions and dx pass (nx / nz are consumed: no extra registers)
+            if (!GENERIC) issue_row<NCH>(reinterpret_cast<const bf16*>(p.x) + (row + 1) * p.ldx, (int)p.C, lane, nx);
+            issue_row<NCH>(reinterpret_cast<const bf16*>(b.dz) + (row + 1) * b.lddz, (int)p.C, lane, nz);
+            nmean = reinterpret_cast<const float*>(p.mean)[row + 1];
+            nrstd = reinterpret_cast<const float*>(p.rstd)[row + 1];
         }
         s1 = wave_sum(s1) * invC;
         s2 = wave_sum(s2) * invC;
@@ -277,22 +319,18 @@ __global__ __launch_bounds__(256) void qkln_fwd_kernel(bf16* buf, int64_t rows, 
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float invC = 1.f / (float)C;
+    bf16x8 nxt[NCH];
+    if (wave < rows) issue_row<NCH>(buf + wave * ld + col0, C, lane, nxt);
     for (int64_t row = wave; row < rows; row += nwaves) {
         bf16* r = buf + row * ld + col0;
         float v[NCH][8];
+        unpack_row<NCH>(nxt, v);
+        if (row + nwaves < rows) issue_row<NCH>(buf + (row + nwaves) * ld + col0, C, lane, nxt);
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = lane * 8 + j * 512;
-            if (c < C) {
-                const bf16x8 h = ld_bf16x8(r + c);
+        for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[j][e] = bf2f(h[e]);
-                    s += v[j][e];
-                }
-            }
-        }
+            for (int e = 0; e < 8; ++e) s += v[j][e];          // columns >= C were loaded as zeros
         const float mean = wave_sum(s) * invC;
         float q = 0.f;
 #pragma unroll
@@ -329,29 +367,34 @@ __global__ __launch_bounds__(256) void qkln_bwd_kernel(bf16* d, int64_t ldd, int
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float invC = 1.f / (float)C;
+    bf16x8 ng[NCH], ny[NCH];
+    float nrstd = 0.f;
+    if (wave < rows) {
+        issue_row<NCH>(d + wave * ldd + dcol0, C, lane, ng);
+        issue_row<NCH>(y + wave * ldy + ycol0, C, lane, ny);
+        nrstd = rstd_in[wave];
+    }
     for (int64_t row = wave; row < rows; row += nwaves) {
         bf16* dr = d + row * ldd + dcol0;
-        const bf16* yr = y + row * ldy + ycol0;
         float g[NCH][8], xh[NCH][8];
+        unpack_row<NCH>(ng, g);
+        unpack_row<NCH>(ny, xh);
+        const float rstd = nrstd;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = lane * 8 + j * 512;
-            if (c < C) {
-                const bf16x8 gv = ld_bf16x8(dr + c);
-                const bf16x8 yv = ld_bf16x8(yr + c);
+        for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    g[j][e] = bf2f(gv[e]);
-                    xh[j][e] = bf2f(yv[e]);
-                    s1 += g[j][e];
-                    s2 += g[j][e] * xh[j][e];
-                }
+            for (int e = 0; e < 8; ++e) {
+                s1 += g[j][e];
+                s2 += g[j][e] * xh[j][e];
             }
+        if (row + nwaves < rows) {
+            issue_row<NCH>(d + (row + nwaves) * ldd + dcol0, C, lane, ng);
+            issue_row<NCH>(y + (row + nwaves) * ldy + ycol0, C, lane, ny);
+            nrstd = rstd_in[row + nwaves];
         }
         s1 = wave_sum(s1) * invC;
         s2 = wave_sum(s2) * invC;
-        const float rstd = rstd_in[row];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane * 8 + j * 512;
