@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout -k 5 300 python -m pytest tests/test_gemm_variants_gpu.py tests/test_gemm_gpu.py -q -x 2>&1 | tail -12 > gpurun_out/c21_pytest.log; tail -4 gpurun_out/c21_pytest.log
+if grep -q "failed\|error" gpurun_out/c21_pytest.log; then grep -B5 "Error\|assert" gpurun_out/c21_pytest.log | head -40; fi
+libs="scratch_libs/lib_plain.so scratch_libs/lib_xpose.so"
+for r in 1 2; do for lib in $libs; do
+  MICRODIT_LIB=$lib timeout -k 5 120 python scripts/bench_gemm_variants.py --variants pp256 --rounds 2 2>&1 | grep -v "amdgpu.ids\|^#" > gpurun_out/c21_$(basename $lib .so)_$r.txt
+done; done
+cd gpurun_out
+paste <(cat c21_lib_plain_1.txt) <(awk '{print $NF}' c21_lib_xpose_1.txt) <(awk '{print $NF}' c21_lib_plain_2.txt) <(awk '{print $NF}' c21_lib_xpose_2.txt) | tee c21_ab.log
+cd ..
+for lib in scratch_libs/lib_xpose.so; do
+  MICRODIT_LIB=$lib timeout -k 5 100 python scripts/gemm_pp_timeline.py 65536 1024 1024 1 1 bf16 2>&1 | grep -v amdgpu.ids | grep "shape\|tile 0\|tile 1\|last epi\|exit skew"
+  MICRODIT_LIB=$lib timeout -k 5 100 python scripts/gemm_pp_timeline.py 65536 1024 1024 1 1 res 2>&1 | grep -v amdgpu.ids | grep "shape\|tile 0\|tile 1\|last epi\|exit skew"
+done | tee gpurun_out/c21_timeline.log
