@@ -386,28 +386,60 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
     const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD;
     const int nq32 = (int)((p.Sq + 31) / 32), nk32 = (int)((p.Skv + 31) / 32);
 
-    stage_tile<HD>(sQ, PK, Q, p.ldq, 0, p.Sq, nq32 * 32, tid, nthreads);
-    stage_tile<HD>(sdO, PK, dO, p.lddo, 0, p.Sq, nq32 * 32, tid, nthreads);
-    stage_tile<HD>(sK, PK, K, p.ldk, 0, p.Skv, nk32 * 32, tid, nthreads);
-    stage_tile<HD>(sV, PK, V, p.ldv, 0, p.Skv, nk32 * 32, tid, nthreads);
-    // delta[q] = sum_d dO[q, d] * O[q, d] and lse[q]: 8 lanes per row (HD / 8 chunks of 16 bytes)
+    // Staging: EVERY global load of the workgroup is issued before the first LDS write -- Q, dO, O (3 x ITQ) and K, V (2 x ITK)
+    // 16-byte chunks per thread, all in flight together.  (The first version staged tile by tile in loops with run-time trip
+    // counts: load -> wait -> ds_write per iteration, i.e. ~20 dependent HBM round trips per workgroup, and a workgroup lived
+    // 25-30 us for ~3 us of arithmetic.)  delta = rowsum(dO * O) is formed from the staged registers (dO is read once).
     {
         constexpr int CPR = HD / 8;
+        constexpr int NT = (SQP > SKP ? SQP : SKP) * 2;                 // = blockDim.x
+        constexpr int ITQ = (SQP * CPR + NT - 1) / NT, ITK = (SKP * CPR + NT - 1) / NT;
         const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
-        for (int task = tid; task < nq32 * 32 * CPR; task += nthreads) {
-            const int r = task / CPR, c = task % CPR;
-            float d = 0.f;
-            if (r < p.Sq) {
-                const bf16x8 ov = ld_bf16x8(O + (int64_t)r * p.ldo + c * 8);
-                const bf16x8 gv = ld_bf16x8(dO + (int64_t)r * p.lddo + c * 8);
+        uint4 rq[ITQ], rdo[ITQ], ro[ITQ], rk[ITK], rv[ITK];
+        float rl[ITQ];
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d += bf2f(ov[e]) * bf2f(gv[e]);
+        for (int it = 0; it < ITQ; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            const bool ok = task < SQP * CPR && r < p.Sq;
+            rq[it] = ok ? *reinterpret_cast<const uint4*>(Q + (int64_t)r * p.ldq + c * 8) : z4;
+            rdo[it] = ok ? *reinterpret_cast<const uint4*>(dO + (int64_t)r * p.lddo + c * 8) : z4;
+            ro[it] = ok ? *reinterpret_cast<const uint4*>(O + (int64_t)r * p.ldo + c * 8) : z4;
+            rl[it] = (ok && c == 0) ? LSE[r] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITK; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            const bool ok = task < SKP * CPR && r < p.Skv;
+            rk[it] = ok ? *reinterpret_cast<const uint4*>(K + (int64_t)r * p.ldk + c * 8) : z4;
+            rv[it] = ok ? *reinterpret_cast<const uint4*>(V + (int64_t)r * p.ldv + c * 8) : z4;
+        }
+#pragma unroll
+        for (int it = 0; it < ITQ; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            if (task < SQP * CPR) {
+                *reinterpret_cast<uint4*>(sQ + r * PK + c * 16) = rq[it];
+                *reinterpret_cast<uint4*>(sdO + r * PK + c * 16) = rdo[it];
             }
+            U128 g, o;
+            g.u = rdo[it];
+            o.u = ro[it];
+            float d = 0.f;
 #pragma unroll
-            for (int o = CPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);       // the CPR lanes of a row are adjacent
-            if (c == 0) {
+            for (int e = 0; e < 8; ++e) d += bf2f(o.h[e]) * bf2f(g.h[e]);
+#pragma unroll
+            for (int s2 = CPR / 2; s2 > 0; s2 >>= 1) d += __shfl_xor(d, s2, 64);      // the CPR lanes of a row are adjacent (NT % CPR == 0)
+            if (c == 0 && task < SQP * CPR) {
                 sDlt[r] = d;
-                sLse[r] = r < p.Sq ? LSE[r] : 0.f;
+                sLse[r] = rl[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITK; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            if (task < SKP * CPR) {
+                *reinterpret_cast<uint4*>(sK + r * PK + c * 16) = rk[it];
+                *reinterpret_cast<uint4*>(sV + r * PK + c * 16) = rv[it];
             }
         }
     }
