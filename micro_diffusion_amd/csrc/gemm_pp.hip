@@ -47,46 +47,38 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int EPI>
 __device__ __forceinline__ int epi_prefetch_count(const md_gemm_args& p) {
-    if (EPI == PP_E_RES) return p.gate ? 6 : 4;
+    if (EPI == PP_E_RES) return p.gate ? 5 : 4;
     if (EPI == PP_E_DACT_GELU) return 4;
     return 0;
 }
 
-// Operands of quadrant (IH, JH), requested one phase ahead.  ONE request site per call site of the kernel (no fast / general
-// split here: see asm_load16); rows / columns are clamped into the matrix so every lane issues every load (the counted
-// waits rely on exact instruction counts) -- on interior tiles the clamps are no-ops.
-//   residual: pre[i * 2 + pp]; gate: pre[4 + pp] (rows_per_sample is a multiple of 64, so the 64 rows of a quadrant share one
-//   gate row); activation input: pre[i * 2 + pp].
+// Operands of quadrant (IH, JH), requested one phase ahead, in the STORE-side layout of the quadrant (EpiLane::quad_coords:
+// lane 4 q + k takes piece k of rows rq .. rq + 3 -> 64 contiguous bytes per quad and load, like the stores).  ONE request
+// site per call site of the kernel (no fast / general split here: see asm_load16); rows / columns are clamped into the
+// matrix so every lane issues every load (the counted waits rely on exact instruction counts) -- on interior tiles the
+// clamps are no-ops.
+//   residual / activation input: pre[t] = row rq + t; gate: pre[4] (rows_per_sample is a multiple of 64, so the 64 rows of a
+//   quadrant share one gate row: one 16-byte piece per lane).
 template <int EPI, int IH, int JH>
-__device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan& w, const EpiTile& et, u32x4 (&pre)[6],
+__device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan& w, const EpiTile& et, u32x4 (&pre)[5],
                                              const EpiLane& el) {
     const unsigned ld = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
     const int mlast = w.M - 1 - et.m0;                               // last valid row / first column of the last chunk, tile-relative
     const int nlast = ((w.N - 1) & ~7) - et.n0;
-    int rl, cl;
-    el.coords(rl, cl);
-    unsigned roff[2], coff[2];
+    int rq, cq;
+    el.quad_coords(rq, cq);
+    const int c = cq + JH * 128;
+    const unsigned coff = (unsigned)(c < nlast ? c : nlast);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = rl + IH * 128 + i * 32;
-        roff[i] = (unsigned)(r < mlast ? r : mlast) * ld;
+    for (int t = 0; t < 4; ++t) {
+        const int r = rq + IH * 128 + t;
+        asm_load16(pre[t], et.opbase + ((unsigned)(r < mlast ? r : mlast) * ld + coff) * 2u);
     }
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int c = cl + JH * 128 + pp * 16;
-        coff[pp] = (unsigned)(c < nlast ? c : nlast);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) asm_load16(pre[i * 2 + pp], et.opbase + (roff[i] + coff[pp]) * 2u);
     if (EPI == PP_E_RES && p.gate) {
         int r0 = et.m0 + IH * 128 + el.wrow;                          // wave-uniform: the quadrant's first row
         r0 = r0 < w.M - 1 ? r0 : w.M - 1;
         const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
-        const char* g = et.gbase + (size_t)(srow * (unsigned)p.ldg) * 2;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) asm_load16(pre[4 + pp], g + coff[pp] * 2u);
+        asm_load16(pre[4], et.gbase + ((size_t)(srow * (unsigned)p.ldg) + coff) * 2);
     }
 }
 
@@ -110,7 +102,7 @@ __device__ __forceinline__ void epi_prefetch(const md_gemm_args& p, const PPPlan
 // pieces of 32 different rows per instruction; measurements and the LDS-transposed whole-line variant that did not pay:
 // profiles/r2_gemm_pp256_store_pattern.txt.
 template <int EPI, int IH, int JH, bool PLAIN>
-__device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et, u32x4 (&pre)[6],
+__device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan& w, f32x16 (&acc)[2], const EpiTile& et, u32x4 (&pre)[5],
                                              const EpiLane& el) {
     constexpr bool F32OUT = (EPI == PP_E_F32);
     constexpr int ES = F32OUT ? 4 : 2;
@@ -121,80 +113,99 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
     const int rl = el.wrow + (l & 31) + IH * 128;                 // row / first column inside the tile
     const int cl = el.wcol + (l >> 5) * CW + JH * 128;
     const int mlim = w.M - et.m0, nlim = w.N - et.n0;
-    const unsigned off0 = ((unsigned)rl * ldc + (unsigned)cl) * ES;
-    const unsigned rstep = 32u * ldc * ES;
-    const bool rok[2] = {PLAIN || rl < mlim, PLAIN || rl + 32 < mlim};
     const float alpha = p.alpha;
+    if constexpr (F32OUT) {
+        // fp32 slices (weight gradients, long K): stored straight from the accumulator layout -- a lane's 4 consecutive columns are 16 bytes
+        const unsigned off0 = ((unsigned)rl * ldc + (unsigned)cl) * 4;
+        const unsigned rstep = 32u * ldc * 4;
+        const bool rok[2] = {PLAIN || rl < mlim, PLAIN || rl + 32 < mlim};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned off = i ? off0 + rstep : off0;
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = i ? off0 + rstep : off0;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int x = i * 2 + pp;
-            const bool ok = PLAIN || (rok[i] && cl + pp * 16 < nlim);   // N % 8 == 0: a store of 8 (4) columns is all inside or all outside
-            float v[8];
+            for (int pp = 0; pp < 2; ++pp) {
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = PLAIN ? acc[i][8 * pp + e] : acc[i][8 * pp + e] * alpha;   // (4 v_pk_mul_f32)
-            if (!PLAIN && EPI != PP_E_DACT_GELU && p.bias) {                   // rare (MicroDiT's large layers have no bias): plain loads
-                const int cb = el.wcol + (l >> 5) * 4 + JH * 128 + pp * 16;   // accumulator layout: columns cb + e, cb + 8 + e
-                const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + cb;
+                for (int e = 0; e < 8; ++e) v[e] = PLAIN ? acc[i][8 * pp + e] : acc[i][8 * pp + e] * alpha;
+                if (!PLAIN && p.bias) {
+                    const int cb = el.wcol + (l >> 5) * 4 + JH * 128 + pp * 16;   // accumulator layout: columns cb + e, cb + 8 + e
+                    if (cb < nlim) {
+                        const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + cb;
+                        const float4 b0 = *reinterpret_cast<const float4*>(bp);
+                        const float4 b1 = *reinterpret_cast<const float4*>(bp + 8);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                }
+                float* cp = reinterpret_cast<float*>(et.cbase + pp * 64 + off);
+                if (rok[i] && (PLAIN || cl + pp * 16 < nlim)) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                if (rok[i] && (PLAIN || cl + pp * 16 + 8 < nlim)) *reinterpret_cast<float4*>(cp + 8) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    } else {
+        // bf16 outputs: bf16(alpha * acc + bias) = what nn.Linear returns under autocast, moved into the row-run layout (quad_rows);
+        // everything after the matmul (activation, residual, gate, activation derivative) acts on that bf16 value, as it does
+        // in the reference, in the layout the operands were requested in.
+        uint4 T[4];
+        quad_rows(l, [&](int i, int g, float (&v)[4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = PLAIN ? acc[i][4 * g + e] : acc[i][4 * g + e] * alpha;
+            if (!PLAIN && EPI != PP_E_DACT_GELU && p.bias) {            // rare (MicroDiT's large layers have no bias): plain loads
+                const int cb = el.wcol + JH * 128 + 8 * g + 4 * (l >> 5);
                 if (cb < nlim) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(bp);
-                    const float4 b1 = *reinterpret_cast<const float4*>(bp + 8);
+                    const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + cb);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
             }
-            if constexpr (F32OUT) {
-                float* cp = reinterpret_cast<float*>(et.cbase + pp * 16 * ES + off);
-                if (ok) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                if (PLAIN || (rok[i] && cl + pp * 16 + 8 < nlim)) *reinterpret_cast<float4*>(cp + 8) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-                uint4 out;
-                const unsigned off2 = ((unsigned)(rl + i * 32) * (unsigned)p.ldc2 + (unsigned)cl) * 2u;
-                if constexpr (EPI == PP_E_BF16) {
-                    out = pack_swap8(v);
-                    if (et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = out;
-                } else if constexpr (EPI == PP_E_BF16_GELU) {
-                    if (et.c2base) {
-                        const uint4 lin = pack_swap8(v);
-                        if (ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = lin;
-                    }
+        }, T);
+        int rq, cq;
+        el.quad_coords(rq, cq);
+        rq += IH * 128;
+        cq += JH * 128;
+        const bool cok = PLAIN || cq < nlim;                        // N % 8 == 0: a piece is all inside or all outside
+        const unsigned off0 = ((unsigned)rq * ldc + (unsigned)cq) * 2, off2 = ((unsigned)rq * (unsigned)p.ldc2 + (unsigned)cq) * 2;
+        uint4 gq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
+        if (EPI == PP_E_RES && p.gate) gq = landed(pre[4]);
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2 g = gelu_erf_2(f32x2{v[e], v[e + 1]});
-                        v[e] = g.x;
-                        v[e + 1] = g.y;
-                    }
-                    out = pack_swap8(v);
-                } else if constexpr (EPI == PP_E_RES) {
-                    const uint4 lin = pack_swap8(v);                    // bf16(alpha * acc + bias): what nn.Linear returns under autocast
-                    if (et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + pp * 32 + off2) = lin;
-                    const uint4 rsu = landed(pre[x]);
-                    const uint4 gu = p.gate ? landed(pre[4 + pp]) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
-                    const unsigned lw[4] = {lin.x, lin.y, lin.z, lin.w}, rw[4] = {rsu.x, rsu.y, rsu.z, rsu.w}, gw[4] = {gu.x, gu.y, gu.z, gu.w};
-                    unsigned ow[4];
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = PLAIN || (cok && rq + t < mlim);
+            if (EPI != PP_E_DACT_GELU && et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + (size_t)t * ((unsigned)p.ldc2 * 2u) + off2) = T[t];
+            uint4 out = T[t];
+            if constexpr (EPI == PP_E_BF16_GELU) {
+                float v[8];
+                unpack8(T[t], v);
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) {                      // one packed pair at a time: few live registers
-                        const float y0 = __uint_as_float(lw[h] << 16), y1 = __uint_as_float(lw[h] & 0xffff0000u);
-                        const float r0 = __uint_as_float(rw[h] << 16), r1 = __uint_as_float(rw[h] & 0xffff0000u);
-                        const float g0 = __uint_as_float(gw[h] << 16), g1 = __uint_as_float(gw[h] & 0xffff0000u);
-                        ow[h] = cvt_pk_bf16(r0 + g0 * y0, r1 + g1 * y1);
-                    }
-                    out = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                } else {   // PP_E_DACT_GELU
-                    float ax[8];
-                    swap_unpack8(landed(pre[x]), ax);
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2 d = dgelu_erf_2(f32x2{ax[e], ax[e + 1]});
-                        v[e] *= d.x;
-                        v[e + 1] *= d.y;
-                    }
-                    out = pack_swap8(v);
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 g2 = gelu_erf_2(f32x2{v[e], v[e + 1]});
+                    v[e] = g2.x;
+                    v[e + 1] = g2.y;
                 }
-                if (ok) *reinterpret_cast<uint4*>(et.cbase + pp * 16 * ES + off) = out;
+                out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+            } else if constexpr (EPI == PP_E_RES) {
+                const uint4 rsu = landed(pre[t]);
+                const unsigned lw[4] = {T[t].x, T[t].y, T[t].z, T[t].w}, rw[4] = {rsu.x, rsu.y, rsu.z, rsu.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
+                unsigned ow[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {                          // one packed pair at a time: few live registers
+                    const float y0 = __uint_as_float(lw[h] << 16), y1 = __uint_as_float(lw[h] & 0xffff0000u);
+                    const float r0 = __uint_as_float(rw[h] << 16), r1 = __uint_as_float(rw[h] & 0xffff0000u);
+                    const float g0 = __uint_as_float(gw[h] << 16), g1 = __uint_as_float(gw[h] & 0xffff0000u);
+                    ow[h] = cvt_pk_bf16(r0 + g0 * y0, r1 + g1 * y1);
+                }
+                out = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            } else if constexpr (EPI == PP_E_DACT_GELU) {
+                float v[8], ax[8];
+                unpack8(T[t], v);
+                unpack8(landed(pre[t]), ax);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 d = dgelu_erf_2(f32x2{ax[e], ax[e + 1]});
+                    v[e] *= d.x;
+                    v[e + 1] *= d.y;
+                }
+                out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
             }
+            if (ok) *reinterpret_cast<uint4*>(et.cbase + (size_t)t * (ldc * 2u) + off0) = out;
         }
     }
     // (the accumulators are not cleared here: the first MFMA of the quadrant's next k-loop takes C = 0, PP_MFMA)
@@ -291,11 +302,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     int pf_after = 0;                              // DMA instructions issued after the pending operand prefetch
     EpiTile et = {0, 0, 0, 0, false, nullptr, nullptr, nullptr, nullptr};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the epilogues with prefetched operands are built in the PLAIN form only (two copies of their quadrant body do not fit
+    // the register budget); md_gemm_pp_eligible sends their ragged / biased / scaled problems to the gemm.hip kernels
+    constexpr bool PLAIN_ONLY = EPI == PP_E_RES || EPI == PP_E_DACT_GELU;
     const int npf = epi_prefetch_count<EPI>(p);
     const bool has_ops = npf > 0;
-    u32x4 pre[6];
+    u32x4 pre[5];
 #pragma unroll
-    for (int x = 0; x < 6; ++x) pre[x] = u32x4{0u, 0u, 0u, 0u};
+    for (int x = 0; x < 5; ++x) pre[x] = u32x4{0u, 0u, 0u, 0u};
 
     f32x16 acc[4][2];                              // quadrant q = ih * 2 + jh, row-fragment i
 #pragma unroll
@@ -365,8 +379,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     do {                                                                                                                \
         if (epi_pending) {                                                                                              \
             if (has_ops) { if (pf_after) PP_VMCNT(2); else PP_VMCNT(0); }                                               \
-            if (EPI == PP_E_RES || et.plain) epi_quadrant<EPI, IH, JH, true>(p, w, acc[Q], et, pre, el);                \
-            else epi_quadrant<EPI, IH, JH, EPI == PP_E_RES>(p, w, acc[Q], et, pre, el);                                 \
+            if (PLAIN_ONLY || et.plain) epi_quadrant<EPI, IH, JH, true>(p, w, acc[Q], et, pre, el);                     \
+            else epi_quadrant<EPI, IH, JH, PLAIN_ONLY>(p, w, acc[Q], et, pre, el);                                      \
             if (HAS_NEXT) {                                                                                             \
                 if (has_ops) {                                                                                          \
                     epi_prefetch<EPI, NIH, NJH>(p, w, et, pre, el);                                                     \
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             if (last_pair && has_ops) {
                 // exact count: the 8 younger DMA instructions plus the operand loads just issued are all loads (in order)
                 if (!live) PP_VMCNT(0);
-                else if (npf == 6) PP_VMCNT(14);
+                else if (npf == 5) PP_VMCNT(13);
                 else PP_VMCNT(12);
             } else {
                 if (live) PP_VMCNT(8); else PP_VMCNT(0);
@@ -482,8 +496,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
    
 #define PP_DRAIN_Q(IH, JH, Q)                                                                                           \
     do {                                                                                                                \
-        if (EPI == PP_E_RES || et.plain) epi_quadrant<EPI, IH, JH, true>(p, w, acc[Q], et, pre, el);                    \
-        else epi_quadrant<EPI, IH, JH, EPI == PP_E_RES>(p, w, acc[Q], et, pre, el);                                     \
+        if (PLAIN_ONLY || et.plain) epi_quadrant<EPI, IH, JH, true>(p, w, acc[Q], et, pre, el);                         \
+        else epi_quadrant<EPI, IH, JH, PLAIN_ONLY>(p, w, acc[Q], et, pre, el);                                          \
     } while (0)
 #define PP_DRAIN_PF(IH, JH)                                                                                             \
     do {                                                                                                                \
@@ -532,7 +546,8 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     if (kspan < 128 || kspan % 128) return false;
     if (a->N % 8) return false;                                  // 16-byte column chunks everywhere
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
-    if (epi == PP_E_RES && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT)) return false;   // only the PLAIN form is built
+    if ((epi == PP_E_RES || epi == PP_E_DACT_GELU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
+        return false;                                            // only the PLAIN form of these two epilogues is built
     if (a->M >= (1 << 30) || a->N >= (1 << 30) || a->K >= (1 << 30)) return false;
     if (a->lda > (1 << 22) || a->ldb > (1 << 22)) return false;  // 32-bit per-lane DMA offsets
     if (a->ldc > (1 << 20) || a->ldc2 > (1 << 20) || a->ldr > (1 << 20) || a->ldaux > (1 << 20) || a->ldg > (1 << 20))

@@ -186,11 +186,20 @@ struct EpiLane {
     int lane, wrow, wcol;   // wrow = wr * 64, wcol = wc * 32: this wave's strip inside a 128-wide half (wave-uniform)
     // rl / cl are recomputed from the lane id at every use (behind an asm, so they are not hoisted into loop-invariant
     // registers): every VGPR that lives across the main loop is one the fragment / prefetch registers cannot have.
-    __device__ __forceinline__ void coords(int& rl, int& cl) const {
+    __device__ __forceinline__ void coords(int& rl, int& cl) const {          // accumulator-side geometry (fp32 slices, bias)
         int l = lane;
         asm volatile("" : "+v"(l));
         rl = wrow + (l & 31);
         cl = wcol + (l >> 5) * 8;
+    }
+    // Store-side geometry of the bf16 epilogues (quad_rows below): the four lanes of quad q = lane / 4 hold the four
+    // 16-byte pieces (k = lane % 4) of rows rq .. rq + 3 of the quadrant, rq = (q / 8) * 32 + (q % 8) * 4.
+    __device__ __forceinline__ void quad_coords(int& rq, int& cq) const {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int q = l >> 2;
+        rq = wrow + (q >> 3) * 32 + (q & 7) * 4;
+        cq = wcol + (l & 3) * 8;
     }
 };
 
@@ -244,6 +253,55 @@ __device__ __forceinline__ void swap_unpack8(uint4 u, float (&f)[8]) {
     half_swap(u.x, u.z);
     half_swap(u.y, u.w);
     unpack8(u, f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// quad_rows: one 64 x 32 quadrant (acc[2] = its two 32-row fragments) as bf16 in a layout whose STORES are runs of 64
+// contiguous bytes.  Straight out of the MFMA a lane owns 16-byte pieces of one row and a store instruction covers 32 rows x
+// 32 bytes -- 64 separate write requests per instruction; with the four lanes of a quad writing one 64-byte run the same
+// bytes cost half (profiles/r2_gemm_pp256_store_pattern.txt: 4.4 -> 2.2 us per tile), and unlike a transposition through
+// LDS this one uses only the VALU, which has slack in an epilogue phase:
+//   1. pack to bf16 pairs; 8 x v_permlane32_swap between the two row fragments: lane L then owns ALL 32 columns (four pieces
+//      W[0..3]) of row 32 (L / 32) + L % 32;
+//   2. a 4 x 4 transpose of 16-byte elements inside each quad, two butterfly stages of 16 DPP moves + selects: lane 4 q + k
+//      ends with piece k of the quad's four rows, T[t] = row rq + t (EpiLane::quad_coords).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned quad_mov(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint4 quad_sel(bool take_nb, const uint4& own, const uint4& nb) { return take_nb ? nb : own; }
+template <int CTRL>
+__device__ __forceinline__ uint4 quad_mov4(const uint4& v) {
+    return make_uint4(quad_mov<CTRL>(v.x), quad_mov<CTRL>(v.y), quad_mov<CTRL>(v.z), quad_mov<CTRL>(v.w));
+}
+template <typename F>
+__device__ __forceinline__ void quad_rows(int l, F&& block, uint4 (&T)[4]) {
+    // block(i, g, v[4]): the lane's fp32 values of fragment i, column group g (columns 8 g + 4 hi + e), already scaled / biased
+    unsigned A[4][2], B[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v0[4], v1[4];
+        block(0, g, v0);
+        block(1, g, v1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            A[g][d] = cvt_pk_bf16(v0[2 * d], v0[2 * d + 1]);
+            B[g][d] = cvt_pk_bf16(v1[2 * d], v1[2 * d + 1]);
+            half_swap(A[g][d], B[g][d]);        // A: columns 8 g + 2 d (+1), B: columns 8 g + 4 + 2 d (+1) of this lane's row
+        }
+    }
+    uint4 W[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) W[g] = make_uint4(A[g][0], A[g][1], B[g][0], B[g][1]);
+    constexpr int X1 = 0xB1, X2 = 0x4E;         // quad_perm [1,0,3,2] / [2,3,0,1]: the lane that differs in bit 0 / bit 1
+    const bool odd = (l & 1) != 0, hi2 = (l & 2) != 0;
+    const uint4 U0 = quad_sel(odd, W[0], quad_mov4<X1>(W[1])), U1 = quad_sel(!odd, W[1], quad_mov4<X1>(W[0]));
+    const uint4 V0 = quad_sel(odd, W[2], quad_mov4<X1>(W[3])), V1 = quad_sel(!odd, W[3], quad_mov4<X1>(W[2]));
+    T[0] = quad_sel(hi2, U0, quad_mov4<X2>(V0));
+    T[1] = quad_sel(hi2, U1, quad_mov4<X2>(V1));
+    T[2] = quad_sel(!hi2, V0, quad_mov4<X2>(U0));
+    T[3] = quad_sel(!hi2, V1, quad_mov4<X2>(U1));
 }
 
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")

@@ -47,7 +47,7 @@ bad = 0
 for k, v in sites.items():
     loop = collections.Counter(v[True])
     n_sites = max(loop.values()) if loop else 0
-    ok = all(c == n_sites for c in loop.values()) and len(loop) in (4, 6)
+    ok = all(c == n_sites for c in loop.values()) and len(loop) in (4, 5)
     print(f"{k[-38:]}: main-loop operand registers {dict(loop)} -> {'ok' if ok else 'MISMATCH'}")
     bad += not ok
 if any(spills.values()):

@@ -137,3 +137,33 @@ def epilogue_map(wr, wc, IH, JH):
             v = np.concatenate([a2, b2], axis=1)            # v[0..3] = new a, v[4..7] = new b
             res[(i, pp)] = v
     return res
+
+
+def quad_rows_model(wr, wc, IH, JH):
+    """gemm_pp_common.h: quad_rows.  Returns T[t][lane] = list of the 8 (row, col) tags the lane's 16-byte piece holds after
+    (1) packing to pairs, (2) v_permlane32_swap between the two row fragments, (3) the two DPP butterfly stages inside a quad."""
+    def acc_tag(i, r, lane):            # accumulator register r of fragment i (operands swapped: lane <-> row)
+        n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        return (IH * 128 + wr * 64 + i * 32 + (lane & 31), JH * 128 + wc * 32 + n)
+    # packed pairs: P[i][g][d][lane] = (tag of low half, tag of high half)
+    P = [[[[(acc_tag(i, 4 * g + 2 * d, lane), acc_tag(i, 4 * g + 2 * d + 1, lane)) for lane in range(64)] for d in range(2)]
+          for g in range(4)] for i in range(2)]
+    W = [[None] * 64 for _ in range(4)]
+    for g in range(4):
+        AB = []
+        for d in range(2):
+            a, b = list(P[0][g][d]), list(P[1][g][d])      # half_swap(vdst = a, src = b): a[32:] <-> b[:32]
+            a[32:], b[:32] = P[1][g][d][:32], P[0][g][d][32:]
+            AB.append((a, b))
+        for lane in range(64):
+            W[g][lane] = [AB[0][0][lane], AB[1][0][lane], AB[0][1][lane], AB[1][1][lane]]     # dwords x, y, z, w
+    def nb(X, mask):                    # quad_perm: the lane that differs in `mask`
+        return [X[lane ^ mask] for lane in range(64)]
+    def sel(cond, own, other):
+        return [other[lane] if cond(lane) else own[lane] for lane in range(64)]
+    odd, hi2 = (lambda l: l & 1 != 0), (lambda l: l & 2 != 0)
+    nodd, nhi2 = (lambda l: l & 1 == 0), (lambda l: l & 2 == 0)
+    U0, U1 = sel(odd, W[0], nb(W[1], 1)), sel(nodd, W[1], nb(W[0], 1))
+    V0, V1 = sel(odd, W[2], nb(W[3], 1)), sel(nodd, W[3], nb(W[2], 1))
+    T = [sel(hi2, U0, nb(V0, 2)), sel(hi2, U1, nb(V1, 2)), sel(nhi2, V0, nb(U0, 2)), sel(nhi2, V1, nb(U1, 2))]
+    return [[[tag for pair in T[t][lane] for tag in pair] for lane in range(64)] for t in range(4)]

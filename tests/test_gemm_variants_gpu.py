@@ -114,8 +114,11 @@ def test_moe_grouped(hip, variant, Bk, d, f):
     _close(O, torch.einsum("erf,efd->erd", H.float(), W2.float()), what="fc2")
     dO = torch.randn(E, Bk, d, device=dev).to(torch.bfloat16)
     dHp = torch.empty_like(H)
-    assert _run(hip, variant, A=dO, B=W2, C=dHp, aux=Hp, M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d,
-                sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF)
+    ok = _run(hip, variant, A=dO, B=W2, C=dHp, aux=Hp, M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d,
+              sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF)
+    if not ok:      # pp256 builds its operand-carrying epilogues (residual, activation derivative) for interior tiles only
+        assert variant == "pp256" and (Bk % 256 or f % 256)
+        pytest.skip("pp256 refuses the ragged activation-derivative launch (the library's own choice falls back to the 2-stage kernels)")
     xp = Hp.float().requires_grad_(True)
     torch.nn.functional.gelu(xp).sum().backward()
     _close(dHp, torch.einsum("erd,efd->erf", dO.float(), W2.float()) * xp.grad, what="dact")

@@ -31,3 +31,24 @@ def test_epilogue_lane_map():
                                 assert tuple(v[lane, e]) == (row, col + e), (wr, wc, IH, JH, i, pp, lane, e, v[lane, e])
                                 seen[row, col + e] += 1
     assert (seen == 1).all()
+
+
+def test_epilogue_row_run_layout():
+    """quad_rows (bf16 epilogues): after the half-wave swap and the 4 x 4 transpose inside each quad, lane 4 q + k of store t holds
+    the 8 consecutive columns 8 k .. 8 k + 7 of row rq + t, rq = (q / 8) * 32 + (q % 8) * 4 -- i.e. the four lanes of a quad write one
+    64-byte run -- and the four stores of the eight waves cover the 256 x 256 tile exactly once."""
+    seen = np.zeros((256, 256), dtype=np.int32)
+    for wr in range(2):
+        for wc in range(4):
+            for IH in range(2):
+                for JH in range(2):
+                    T = pm.quad_rows_model(wr, wc, IH, JH)
+                    for t in range(4):
+                        for lane in range(64):
+                            q, k = lane >> 2, lane & 3
+                            row = IH * 128 + wr * 64 + (q >> 3) * 32 + (q & 7) * 4 + t        # EpiLane::quad_coords + t
+                            col = JH * 128 + wc * 32 + 8 * k
+                            assert T[t][lane] == [(row, col + e) for e in range(8)], (wr, wc, IH, JH, t, lane, T[t][lane])
+                            for e in range(8):
+                                seen[row, col + e] += 1
+    assert (seen == 1).all()
