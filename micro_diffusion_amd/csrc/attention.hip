@@ -60,6 +60,34 @@ __device__ __forceinline__ void stage_tile(unsigned char* tile, int pitch, const
 constexpr int STG = 32;    // rows staged per barrier phase.  Measured (scripts/bench_attn.py): 32 beats 64 and 128 -- at S = 64..256 these
                            // kernels stream q/k/v/o at 3.4-4.1 TB/s (HBM-bound); bigger phases only cost occupancy (LDS, VGPRs)
 
+// Stage the same `nstage` (<= STG) rows of TWO matrices (K and V, or Q and dO) into their LDS tiles with every global load issued
+// before the first LDS write.  The staging registers cost occupancy (attn_fwd at 4 chunks: 124 -> 176 VGPRs, -20 % on the
+// 256-row shapes), so the kernels are instantiated per chunk count and launched with the smallest that covers their block size.
+// (Two stage_tile calls are two run-time loops of load -> wait -> write: four dependent HBM round trips per phase.)
+template <int HD, int MAXIT>
+__device__ __forceinline__ void stage_pair(unsigned char* tileA, unsigned char* tileB, int pitch, const bf16* A, int64_t lda, const bf16* B,
+                                           int64_t ldb, int64_t row0, int64_t nrows, int nstage, int tid, int nthreads) {
+    constexpr int CPR = HD / 8;                 // MAXIT >= nstage * CPR / nthreads chunks per thread and matrix (the callers pick it)
+    uint4 ra[MAXIT], rb[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int task = tid + it * nthreads, r = task / CPR, c = task % CPR;
+        ra[it] = rb[it] = make_uint4(0, 0, 0, 0);
+        if (task < nstage * CPR && row0 + r < nrows) {
+            ra[it] = *reinterpret_cast<const uint4*>(A + (row0 + r) * lda + c * 8);
+            rb[it] = *reinterpret_cast<const uint4*>(B + (row0 + r) * ldb + c * 8);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int task = tid + it * nthreads, r = task / CPR, c = task % CPR;
+        if (task < nstage * CPR) {
+            *reinterpret_cast<uint4*>(tileA + r * pitch + c * 16) = ra[it];
+            *reinterpret_cast<uint4*>(tileB + r * pitch + c * 16) = rb[it];
+        }
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
     bf16x8 o;
 #pragma unroll
@@ -82,7 +110,7 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
         }
 }
 
-template <int HD>
+template <int HD, int MAXIT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
@@ -114,8 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     for (int64_t kbase = 0; kbase < p.Skv; kbase += STG) {
         __syncthreads();
         const int nst = (int)((p.Skv - kbase >= STG) ? STG : ((p.Skv - kbase + 31) / 32) * 32);
-        stage_tile<HD>(smem, PK, K, p.ldk, kbase, p.Skv, nst, tid, nthreads);
-        stage_tile<HD>(smem + STG * PK, PK, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
+        stage_pair<HD, MAXIT>(smem, smem + STG * PK, PK, K, p.ldk, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
         __syncthreads();
       for (int sub = 0; sub < STG / 32 && kbase + sub * 32 < p.Skv; ++sub) {
         const int64_t key0 = kbase + sub * 32;
@@ -220,8 +247,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
     for (int64_t kbase = 0; kbase < p.Skv; kbase += STG) {
         __syncthreads();
         const int nst = (int)((p.Skv - kbase >= STG) ? STG : ((p.Skv - kbase + 31) / 32) * 32);
-        stage_tile<HD>(smem, PK, K, p.ldk, kbase, p.Skv, nst, tid, nthreads);
-        stage_tile<HD>(smem + STG * PK, PK, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
+        stage_pair<HD, STG * (HD / 8) / 64>(smem, smem + STG * PK, PK, K, p.ldk, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
         __syncthreads();
       for (int sub = 0; sub < STG / 32 && kbase + sub * 32 < p.Skv; ++sub) {
         const int64_t key0 = kbase + sub * 32;
@@ -304,8 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
     for (int64_t qbase = 0; qbase < p.Sq; qbase += STG) {
         __syncthreads();
         const int nst = (int)((p.Sq - qbase >= STG) ? STG : ((p.Sq - qbase + 31) / 32) * 32);
-        stage_tile<HD>(smem, PK, Q, p.ldq, qbase, p.Sq, nst, tid, nthreads);
-        stage_tile<HD>(smem + STG * PK, PK, dO, p.lddo, qbase, p.Sq, nst, tid, nthreads);
+        stage_pair<HD, STG * (HD / 8) / 64>(smem, smem + STG * PK, PK, Q, p.ldq, dO, p.lddo, qbase, p.Sq, nst, tid, nthreads);
         for (int i = tid; i < nst; i += nthreads) {
             const bool v = qbase + i < p.Sq;
             sLseAll[i] = v ? LSE[qbase + i] : 0.f;
@@ -599,10 +624,17 @@ extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a)) return MD_BAD_ARG;
     const int nw = waves_for(a->Sq);
     dim3 grid((unsigned)((a->Sq + 32 * nw - 1) / (32 * nw)), (unsigned)a->H, (unsigned)a->B);
-    if (a->hd == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64 * nw), 0, stream, *a);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64 * nw), 0, stream, *a);
+    // chunks of a 32-row phase per thread and matrix: 32 * hd / 8 / (64 * nw)
+#define FWD(HD_)                                                                                                  \
+    do {                                                                                                           \
+        const int chunks = (32 * (HD_ / 8) + 64 * nw - 1) / (64 * nw);                                             \
+        if (chunks <= 1) hipLaunchKernelGGL((attn_fwd_kernel<HD_, 1>), grid, dim3(64 * nw), 0, stream, *a);        \
+        else if (chunks == 2) hipLaunchKernelGGL((attn_fwd_kernel<HD_, 2>), grid, dim3(64 * nw), 0, stream, *a);   \
+        else hipLaunchKernelGGL((attn_fwd_kernel<HD_, 4>), grid, dim3(64 * nw), 0, stream, *a);                    \
+    } while (0)
+    if (a->hd == 64) FWD(64);
+    else FWD(32);
+#undef FWD
     MD_LAUNCH_CHECK();
     return 0;
 }
