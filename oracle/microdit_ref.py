@@ -497,6 +497,22 @@ def synth_batch(cfg: RefConfig, B: int, seed: int, cap_len: int = 77, mask_ratio
     return {"image_latents": lat, "caption_latents": cap, "drop_caption_mask": drop}, rnd, epsn, mnoise
 
 
+def dezero_state_dict(sd: SD, seed: int = 4321, std: float = 0.02) -> SD:
+    """The reference zero-initialises every adaLN / final-layer / caption-block output weight (dit.py:577-627), which makes
+    the network contribute almost nothing for the first thousand steps.  The "hot" loss-curve parity run
+    (tests/golden/tiny_curve_hot.npz) starts from the same seed-18 initialisation with every all-zero tensor replaced by
+    N(0, std^2) noise drawn from its own seeded CPU generator (keys in sorted order)."""
+    out = {}
+    for i, k in enumerate(sorted(sd)):
+        v = sd[k]
+        if v.is_floating_point() and v.numel() > 1 and float(v.abs().max()) == 0.0:
+            g = torch.Generator().manual_seed(seed + i)
+            out[k] = (torch.randn(v.shape, generator=g) * std).to(v.dtype)
+        else:
+            out[k] = v.clone()
+    return out
+
+
 def curve_inputs(cfg: RefConfig, step: int, batch: int = 16, pool: int = 64, pool_seed: int = 77):
     """Deterministic data + noise of step `step` of the 1k-step loss-curve parity run (tests/golden/tiny_curve_1k.npz):
     a fixed pool of `pool` synthetic samples cycled in order, and per-step noise from its own CPU generator."""
