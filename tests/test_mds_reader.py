@@ -301,3 +301,58 @@ def test_loader_resume_mid_epoch(shards):
     c = mdata.LatentsLoader(ds, 8, device="cpu", rank=0, world_size=1, seed=9)
     c.load_state_dict({"epoch": 2, "batch_in_epoch": 6})
     assert (c.epoch, c.batch_in_epoch) == (3, 0)
+
+
+def test_hand_assembled_shard_byte_for_byte(tmp_path):
+    """An independent pin of the shard layout (§8f-1 was checked against one restatement only).  The shard below is
+    assembled BYTE BY BYTE here with struct.pack from the published MDS v2 layout -- it shares no code with oracle/mds_ref.py's
+    writer -- and both readers (the native one through the C ABI and the oracle's) must return exactly the values that went in:
+      u32 n | u32 absolute offsets[n + 1] | column-config JSON | per sample: u32 size of every VARIABLE-size column (column order),
+      then the column values in column order.  Columns are stored sorted by name; "int" is the fixed-size (8-byte) case, which
+      has no entry in the per-sample size header."""
+    import struct
+    names = ["caption", "caption_latents", "idx", "latents_256"]                 # sorted, as MDSWriter stores them
+    encs = ["str", "bytes", "int", "bytes"]
+    sizes = [None, None, 8, None]
+    rng = np.random.default_rng(7)
+    rows = []
+    for i, cap in enumerate(["a photo of a cat", "", "zwölf Boxkämpfer jagen Viktor"]):     # empty and multi-byte UTF-8 captions
+        rows.append({"caption": cap, "caption_latents": rng.standard_normal((1, 77, 8)).astype(np.float16).tobytes(),
+                     "idx": 1000 + i, "latents_256": rng.standard_normal((4, 32, 32)).astype(np.float16).tobytes()})
+    cfg = json.dumps({"column_encodings": encs, "column_names": names, "column_sizes": sizes}, sort_keys=True).encode()
+    blobs = []
+    for r in rows:
+        vals = [r["caption"].encode("utf-8"), r["caption_latents"], struct.pack("<q", r["idx"]), r["latents_256"]]
+        head = b"".join(struct.pack("<I", len(v)) for v, s in zip(vals, sizes) if s is None)      # 3 variable columns -> 12 bytes
+        assert len(head) == 12
+        blobs.append(head + b"".join(vals))
+    n = len(blobs)
+    first = 4 + 4 * (n + 1) + len(cfg)
+    offs, cur = [], first
+    for b in blobs:
+        offs.append(cur)
+        cur += len(b)
+    offs.append(cur)
+    shard = struct.pack("<I", n) + struct.pack(f"<{n + 1}I", *offs) + cfg + b"".join(blobs)
+    assert len(shard) == offs[-1]
+    d = tmp_path / "hand"
+    d.mkdir()
+    (d / "shard.00000.mds").write_bytes(shard)
+    (d / "index.json").write_text(json.dumps({"version": 2, "shards": [{
+        "column_encodings": encs, "column_names": names, "column_sizes": sizes, "compression": None, "format": "mds", "hashes": [],
+        "raw_data": {"basename": "shard.00000.mds", "bytes": len(shard), "hashes": {}}, "samples": n, "size_limit": 1 << 26,
+        "version": 2, "zip_data": None}]}))
+    m = mds.MDSDir(str(d))
+    r = mds_ref.RefMDSReader(str(d))
+    assert len(m) == len(r) == n and m.column_names == names and m.column_encodings == encs
+    for i, row in enumerate(rows):
+        assert r[i] == row
+        assert m.read_value(i, m.column("caption")).decode("utf-8") == row["caption"]
+        assert m.read_value(i, m.column("caption_latents")) == row["caption_latents"]
+        assert struct.unpack("<q", m.read_value(i, m.column("idx")))[0] == row["idx"]
+        assert m.read_value(i, m.column("latents_256")) == row["latents_256"]
+    # the batched gather the loader uses: rows 2, 0, 2 of the 8 KiB latents column straight into a strided destination
+    dst = np.zeros((3, 4 * 32 * 32 + 5), dtype=np.float16)
+    m.read_batch(np.array([2, 0, 2], dtype=np.int64), m.column("latents_256"), dst.ctypes.data, 4 * 32 * 32 * 2, dst.strides[0], 2)
+    for k, i in enumerate([2, 0, 2]):
+        assert dst[k, :4096].tobytes() == rows[i]["latents_256"] and not dst[k, 4096:].any()
