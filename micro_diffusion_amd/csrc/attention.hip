@@ -16,6 +16,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x4 tr4(const unsigned char* p) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
@@ -110,8 +111,11 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
         }
 }
 
+// Register budget: with up to two staging chunks per thread the kernel fits 128 VGPRs without spilling (117 at head_dim 64), i.e.
+// 4 waves / SIMD instead of the 3 the unconstrained allocation (136) allows; workgroups here are 2-4 waves of serial
+// load -> MFMA -> softmax chains, so resident waves are what hides their latency.
 template <int HD, int MAXIT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXIT <= 2 ? 4 : 1))) void attn_fwd_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
@@ -420,38 +424,36 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
         constexpr int NT = (SQP > SKP ? SQP : SKP) * 2;                 // = blockDim.x
         constexpr int ITQ = (SQP * CPR + NT - 1) / NT, ITK = (SKP * CPR + NT - 1) / NT;
         const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
-        uint4 rq[ITQ], rdo[ITQ], ro[ITQ], rk[ITK], rv[ITK];
+        u32x4 rq[ITQ], rdo[ITQ], ro[ITQ], rk[ITK], rv[ITK];
         float rl[ITQ];
-        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int it = 0; it < ITQ; ++it) {
             const int task = tid + it * NT, r = task / CPR, c = task % CPR;
             const bool ok = task < SQP * CPR && r < p.Sq;
-            rq[it] = ok ? *reinterpret_cast<const uint4*>(Q + (int64_t)r * p.ldq + c * 8) : z4;
-            rdo[it] = ok ? *reinterpret_cast<const uint4*>(dO + (int64_t)r * p.lddo + c * 8) : z4;
-            ro[it] = ok ? *reinterpret_cast<const uint4*>(O + (int64_t)r * p.ldo + c * 8) : z4;
+            rq[it] = ok ? *reinterpret_cast<const u32x4*>(Q + (int64_t)r * p.ldq + c * 8) : z4;
+            rdo[it] = ok ? *reinterpret_cast<const u32x4*>(dO + (int64_t)r * p.lddo + c * 8) : z4;
+            ro[it] = ok ? *reinterpret_cast<const u32x4*>(O + (int64_t)r * p.ldo + c * 8) : z4;
             rl[it] = (ok && c == 0) ? LSE[r] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < ITK; ++it) {
             const int task = tid + it * NT, r = task / CPR, c = task % CPR;
             const bool ok = task < SKP * CPR && r < p.Skv;
-            rk[it] = ok ? *reinterpret_cast<const uint4*>(K + (int64_t)r * p.ldk + c * 8) : z4;
-            rv[it] = ok ? *reinterpret_cast<const uint4*>(V + (int64_t)r * p.ldv + c * 8) : z4;
+            rk[it] = ok ? *reinterpret_cast<const u32x4*>(K + (int64_t)r * p.ldk + c * 8) : z4;
+            rv[it] = ok ? *reinterpret_cast<const u32x4*>(V + (int64_t)r * p.ldv + c * 8) : z4;
         }
 #pragma unroll
         for (int it = 0; it < ITQ; ++it) {
             const int task = tid + it * NT, r = task / CPR, c = task % CPR;
             if (task < SQP * CPR) {
-                *reinterpret_cast<uint4*>(sQ + r * PK + c * 16) = rq[it];
-                *reinterpret_cast<uint4*>(sdO + r * PK + c * 16) = rdo[it];
+                *reinterpret_cast<u32x4*>(sQ + r * PK + c * 16) = rq[it];
+                *reinterpret_cast<u32x4*>(sdO + r * PK + c * 16) = rdo[it];
             }
-            U128 g, o;
-            g.u = rdo[it];
-            o.u = ro[it];
+            const bf16x8 g = __builtin_bit_cast(bf16x8, rdo[it]), o = __builtin_bit_cast(bf16x8, ro[it]);
             float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d += bf2f(o.h[e]) * bf2f(g.h[e]);
+            for (int e = 0; e < 8; ++e) d += bf2f(o[e]) * bf2f(g[e]);
 #pragma unroll
             for (int s2 = CPR / 2; s2 > 0; s2 >>= 1) d += __shfl_xor(d, s2, 64);      // the CPR lanes of a row are adjacent (NT % CPR == 0)
             if (c == 0 && task < SQP * CPR) {
@@ -463,8 +465,8 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
         for (int it = 0; it < ITK; ++it) {
             const int task = tid + it * NT, r = task / CPR, c = task % CPR;
             if (task < SKP * CPR) {
-                *reinterpret_cast<uint4*>(sK + r * PK + c * 16) = rk[it];
-                *reinterpret_cast<uint4*>(sV + r * PK + c * 16) = rv[it];
+                *reinterpret_cast<u32x4*>(sK + r * PK + c * 16) = rk[it];
+                *reinterpret_cast<u32x4*>(sV + r * PK + c * 16) = rv[it];
             }
         }
     }
@@ -585,16 +587,248 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-phase fused backward: the same arithmetic and the same one-launch-per-(batch, head) traffic as attn_bwd_fused_kernel,
+// with HALF its LDS image and a register budget of 3 waves / SIMD.  The single-phase kernel keeps Q, dO, K and V in LDS
+// together (37-47 KiB at S <= 96) and needs 220 VGPRs, which leaves a CU with 6-8 resident waves; at these sizes a workgroup is
+// a serial chain (load -> LDS -> ~60 dependent MFMAs -> store) whose only overlap is with OTHER workgroups, so throughput
+// follows the number of workgroups a CU can hold.  Here ONE pair of tiles is alive at a time:
+//   P1  Q, dO -> LDS (and delta = rowsum(dO * O), lse);  P2  every wave lifts its own 32 query rows into registers;
+//   P3  K, V overwrite the image;  P4  dQ (role 1), then every wave lifts its own 32 key rows;
+//   P5  the waves write their query rows back (the registers are the only copy: nothing is re-read from HBM);
+//   P6  dK, dV (role 2).
+// LDS: 2 * max(SQP, SKP) * (HD + 8) * 2 bytes + lse / delta (18.9 KiB at 64 x 64, 28.2 KiB with 77 keys).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD, int SQP, int SKP>
+__global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) __attribute__((amdgpu_waves_per_eu(3)))
+void attn_bwd_fused2_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    constexpr int RMAX = SQP > SKP ? SQP : SKP;
+    constexpr int NT = RMAX * 2;                                       // = blockDim.x: one wave per 32 rows of the taller side
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RMAX * PK + 2 * SQP * 4];
+    unsigned char* sA = smem;                     // Q, later K
+    unsigned char* sB = smem + RMAX * PK;         // dO, later V
+    float* sLse = reinterpret_cast<float*>(smem + 2 * RMAX * PK);
+    float* sDlt = sLse + SQP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.y, h = blockIdx.x;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD;
+    const int nq32 = (int)((p.Sq + 31) / 32), nk32 = (int)((p.Skv + 31) / 32);
+
+    constexpr int CPR = HD / 8;
+    constexpr int ITQ = (SQP * CPR + NT - 1) / NT, ITK = (SKP * CPR + NT - 1) / NT;
+    u32x4 rk[ITK], rv[ITK];
+    {
+        // every global load of the workgroup in flight before the first LDS write (as in the single-phase kernel)
+        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
+        u32x4 rq[ITQ], rdo[ITQ], ro[ITQ];
+        float rl[ITQ];
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < ITQ; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            const bool ok = task < SQP * CPR && r < p.Sq;
+            rq[it] = ok ? *reinterpret_cast<const u32x4*>(Q + (int64_t)r * p.ldq + c * 8) : z4;
+            rdo[it] = ok ? *reinterpret_cast<const u32x4*>(dO + (int64_t)r * p.lddo + c * 8) : z4;
+            ro[it] = ok ? *reinterpret_cast<const u32x4*>(O + (int64_t)r * p.ldo + c * 8) : z4;
+            rl[it] = (ok && c == 0) ? LSE[r] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITK; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            const bool ok = task < SKP * CPR && r < p.Skv;
+            rk[it] = ok ? *reinterpret_cast<const u32x4*>(K + (int64_t)r * p.ldk + c * 8) : z4;
+            rv[it] = ok ? *reinterpret_cast<const u32x4*>(V + (int64_t)r * p.ldv + c * 8) : z4;
+        }
+        // ---- P1: Q, dO -> LDS; delta from the staged registers
+#pragma unroll
+        for (int it = 0; it < ITQ; ++it) {
+            const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+            if (task < SQP * CPR) {
+                *reinterpret_cast<u32x4*>(sA + r * PK + c * 16) = rq[it];
+                *reinterpret_cast<u32x4*>(sB + r * PK + c * 16) = rdo[it];
+            }
+            const bf16x8 g = __builtin_bit_cast(bf16x8, rdo[it]), o = __builtin_bit_cast(bf16x8, ro[it]);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += bf2f(o[e]) * bf2f(g[e]);
+#pragma unroll
+            for (int s2 = CPR / 2; s2 > 0; s2 >>= 1) d += __shfl_xor(d, s2, 64);      // the CPR lanes of a row are adjacent (NT % CPR == 0)
+            if (c == 0 && task < SQP * CPR) {
+                sDlt[r] = d;
+                sLse[r] = rl[it];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P2: this wave's 32 query rows as MFMA operand fragments
+    const bool qrole = wave < nq32, krole = wave < nk32;
+    bf16x8 qf[HD / 16], dof[HD / 16];
+    float lse = 0.f, dlt = 0.f;
+    if (qrole) {
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            qf[s] = row_frag(sA + wave * 32 * PK, PK, s * 16, lane);
+            dof[s] = row_frag(sB + wave * 32 * PK, PK, s * 16, lane);
+        }
+        lse = sLse[wave * 32 + (lane & 31)];
+        dlt = sDlt[wave * 32 + (lane & 31)];
+    }
+    __syncthreads();
+    // ---- P3: K, V take the place of Q, dO
+#pragma unroll
+    for (int it = 0; it < ITK; ++it) {
+        const int task = tid + it * NT, r = task / CPR, c = task % CPR;
+        if (task < SKP * CPR) {
+            *reinterpret_cast<u32x4*>(sA + r * PK + c * 16) = rk[it];
+            *reinterpret_cast<u32x4*>(sB + r * PK + c * 16) = rv[it];
+        }
+    }
+    __syncthreads();
+    // ---- P4 role 1: dQ for query rows wave * 32 ..
+    if (qrole) {
+        const int64_t q = (int64_t)wave * 32 + (lane & 31);
+        f32x16 dqacc[HD / 32];
+#pragma unroll
+        for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
+        for (int j = 0; j < nk32; ++j) {
+            const unsigned char* tK = sA + j * 32 * PK;
+            const unsigned char* tV = sB + j * 32 * PK;
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t key = (int64_t)j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
+                sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(sacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di)
+                    dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
+            }
+        }
+        if (q < p.Sq) {
+            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+            store_rows<HD>(dQ, dqacc, 1.f, lane);
+        }
+    }
+    // this wave's 32 key rows, while K and V are still in LDS
+    bf16x8 kf[HD / 16], vf[HD / 16];
+    if (krole) {
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            kf[s] = row_frag(sA + wave * 32 * PK, PK, s * 16, lane);
+            vf[s] = row_frag(sB + wave * 32 * PK, PK, s * 16, lane);
+        }
+    }
+    __syncthreads();
+    // ---- P5: the query rows go back (row_frag's inverse: lane -> row lane & 31, 16-byte column group s * 2 + hh)
+    if (qrole) {
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            *reinterpret_cast<u32x4*>(sA + (wave * 32 + (lane & 31)) * PK + (s * 16 + hh * 8) * 2) = __builtin_bit_cast(u32x4, qf[s]);
+            *reinterpret_cast<u32x4*>(sB + (wave * 32 + (lane & 31)) * PK + (s * 16 + hh * 8) * 2) = __builtin_bit_cast(u32x4, dof[s]);
+        }
+    }
+    __syncthreads();
+    // ---- P6 role 2: dK, dV for key rows wave * 32 ..
+    if (krole) {
+        const int64_t key = (int64_t)wave * 32 + (lane & 31);
+        f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+        for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[di][r] = 0.f;
+                dvacc[di][r] = 0.f;
+            }
+        for (int i = 0; i < nq32; ++i) {
+            const unsigned char* tQ = sA + i * 32 * PK;
+            const unsigned char* tdO = sB + i * 32 * PK;
+            const float* tLse = sLse + i * 32;
+            const float* tDlt = sDlt + i * 32;
+            f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
+                sacc[r] = pr;                                           // P
+                dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc, 8 * sp);
+                const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di) {
+                    dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
+                    dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+                }
+            }
+        }
+        if (key < p.Skv) {
+            bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
+            bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+            store_rows<HD>(dK, dkacc, 1.f, lane);
+            store_rows<HD>(dV, dvacc, 1.f, lane);
+        }
+    }
+}
+
 // Padded row-count bucket of the fused backward: 64, 96 or 256 (0 = not covered)
 inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 256 ? 256 : 0; }
 
+// variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image (row counts <= 96 only),
+// 0 = the rule: two-phase where it exists (it doubles the resident workgroups of the backbone shapes), single-phase for the
+// 256-row buckets (8-wave workgroups: the register budget, not LDS, holds those at one workgroup per CU either way).
 template <int HD>
-bool launch_bwd_fused(const md_attn_args* a, hipStream_t stream) {
+bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
     if (!bq || !bk) return false;
+    const bool small = bq <= 96 && bk <= 96;
+    if (variant == 3 && !small) return false;
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-    if (bq == 64 && bk == 64) FUSED(64, 64);
+#define FUSED2(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
+    if (small && variant != 2) {
+        if (bq == 64 && bk == 64) FUSED2(64, 64);
+        else if (bq == 64 && bk == 96) FUSED2(64, 96);
+        else if (bq == 96 && bk == 64) FUSED2(96, 64);
+        else FUSED2(96, 96);
+    }
+    else if (bq == 64 && bk == 64) FUSED(64, 64);
     else if (bq == 64 && bk == 96) FUSED(64, 96);
     else if (bq == 96 && bk == 64) FUSED(96, 64);
     else if (bq == 96 && bk == 96) FUSED(96, 96);
@@ -604,6 +838,7 @@ bool launch_bwd_fused(const md_attn_args* a, hipStream_t stream) {
     else if (bq == 256 && bk == 64) FUSED(256, 64);
     else FUSED(96, 256);
 #undef FUSED
+#undef FUSED2
     return true;
 }
 
@@ -643,9 +878,13 @@ extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
     // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
-    if (a->bwd_split == 0 && (a->hd == 64 ? launch_bwd_fused<64>(a, stream) : launch_bwd_fused<32>(a, stream))) {
-        MD_LAUNCH_CHECK();
-        return 0;
+    if (a->bwd_split < 0 || a->bwd_split > 3) return MD_BAD_ARG;
+    if (a->bwd_split != 1) {
+        if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
+            MD_LAUNCH_CHECK();
+            return 0;
+        }
+        if (a->bwd_split != 0) return -1;      // a forced fused variant that does not cover this problem: nothing was launched
     }
     const int nwq = waves_for(a->Sq), nwk = waves_for(a->Skv);
     dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);

@@ -96,6 +96,7 @@ class DiTEngine:
         self.wgrad_target_blocks = 768
         self.gemm_profile = None
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
+        self.attn_bwd_prefer = hip.ATTN_BWD_AUTO   # same for the attention backward (md_attn_args.bwd_split)
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
         self.ws = torch.empty(128 << 20, device=self.dev, dtype=F32)  # 512 MiB split-K workspace
         # Fixed-address activation memory (opt-in: the caller must run forward -> backward strictly in turn, as the Trainer
@@ -264,6 +265,16 @@ class DiTEngine:
                             Sq * ldq, Skv * ldk, Skv * ldv, Sq * hid, lddq, lddk, lddv, hid, Sq * lddq, Skv * lddk,
                             Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd, 0)
 
+    def _attn_bwd(self, a):
+        rc = -1
+        if self.attn_bwd_prefer != hip.ATTN_BWD_AUTO:
+            a.bwd_split = self.attn_bwd_prefer
+            rc = self.L.md_attn_bwd(byref(a), self._st())     # -1: the forced kernel does not cover this problem (nothing launched)
+            a.bwd_split = hip.ATTN_BWD_AUTO
+        if rc == -1:
+            rc = self.L.md_attn_bwd(byref(a), self._st())
+        hip.check(rc, "md_attn_bwd")
+
     # ------------------------------------------------------------------------------------------ attention layers
     def _self_attn_fwd(self, pre, xin, B, S, dim, hid, heads, t):
         """xin [B*S, dim] -> o [B*S, hid]; saves qkv (post-LN), rstd, lse on tape t."""
@@ -290,7 +301,7 @@ class DiTEngine:
         a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, t.o, t.lse, B, heads, S, S,
                            3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
                            dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
-        hip.check(L.md_attn_bwd(byref(a), st), "md_attn_bwd")
+        self._attn_bwd(a)
         hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq[0].data_ptr(), st), "qkln bwd")
         hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, hid, qkv.data_ptr(), 3 * hid, hid, M, hid, t.rq[1].data_ptr(), st), "qkln bwd")
         self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim)
@@ -462,7 +473,7 @@ class DiTEngine:
         ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, hx,
                             2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
                             delta=delta, lddq=hx, lddk=2 * hx, lddv=2 * hx)
-        hip.check(L.md_attn_bwd(byref(ax), st), "md_attn_bwd")
+        self._attn_bwd(ax)
         hip.check(L.md_qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr(), st), "qkln_bwd")
         hip.check(L.md_qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr(), st), "qkln_bwd")
         self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)

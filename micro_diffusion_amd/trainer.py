@@ -155,12 +155,16 @@ class GradSync:
     The squared norm of every reduced segment is taken on a side stream right behind its collective (deterministic partial
     sums, md_sumsq), so the clip coefficient needs no extra pass after the last bucket and is bit-identical on all ranks."""
 
-    def __init__(self, dit, process_group=None, exchange: str = "auto"):
+    def __init__(self, dit, process_group=None, exchange: str = "auto", single_rank_exchange: bool = False):
+        """`single_rank_exchange`: run the whole exchange path (staging cast, asynchronous collective, side-stream norm) also on
+        a process group of ONE rank, where the all-reduce is the identity — the only way to drive the RCCL code path on a box
+        with a single GPU (tests/test_dp_gpu.py); never set in production."""
         self.dit = dit
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1 or (single_rank_exchange and dist.is_initialized())
         if exchange == "auto":
-            exchange = "bf16" if (self.world > 1 and dist.get_backend(process_group) == "nccl") else "fp32"
+            exchange = "bf16" if (self.enabled and dist.get_backend(process_group) == "nccl") else "fp32"
         assert exchange in ("bf16", "fp32")
         self.exchange = exchange
         f = dit.flat_buffers()
@@ -180,12 +184,12 @@ class GradSync:
         self.active = False
         self.buckets = 0                 # buckets handed over in the current step (= partial-sum slots in use)
         self.norm_partials: Optional[torch.Tensor] = None     # set by the Trainer: FusedAdamW.partials
-        self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.world > 1) else None
-        self.side = torch.cuda.Stream(device=f["g"].device) if (self.world > 1 and f["g"].is_cuda) else None
-        self.host_bounce = self.world > 1 and f["g"].is_cuda and dist.get_backend(process_group) != "nccl"
+        self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.enabled) else None
+        self.side = torch.cuda.Stream(device=f["g"].device) if (self.enabled and f["g"].is_cuda) else None
+        self.host_bounce = self.enabled and f["g"].is_cuda and dist.get_backend(process_group) != "nccl"
 
     def describe(self) -> str:
-        if self.world == 1:
+        if not self.enabled:
             return "none (single rank)"
         return f"{self.exchange} all-reduce per backward segment ({len(self.ranges) + 2} buckets), overlapped with backward"
 
@@ -219,7 +223,7 @@ class GradSync:
             self.pending.append(work)
 
     def on_segment(self, name: str) -> None:
-        if not self.active or self.world == 1:
+        if not self.active or not self.enabled:
             return
         for lo, hi in (self._rest_ranges() if name == "rest" else [tuple(self.ranges[name])]):
             self._exchange(lo, hi)
@@ -253,10 +257,10 @@ class GradSync:
 class Trainer:
     def __init__(self, model, optimizer: FusedAdamW, schedule: Optional[LRSchedule] = None, clip_norm: float = 0.0,
                  microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None,
-                 exchange: str = "auto"):
+                 exchange: str = "auto", single_rank_exchange: bool = False):
         self.model, self.opt, self.schedule, self.clip_norm = model, optimizer, schedule, clip_norm
         self.microbatch_size = microbatch_size
-        self.sync = GradSync(model.dit, process_group, exchange=exchange)
+        self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange)
         self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
         model.dit._on_segment = self.sync.on_segment
@@ -285,7 +289,7 @@ class Trainer:
         slots = self.sync.finish()
         fac = self.schedule.factor(self.batches_seen) if self.schedule is not None else 1.0
         self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
-                      g_bf16=self.sync.gbf if self.world > 1 else None, norm_partials=slots * hip.SUMSQ_PARTIALS)
+                      g_bf16=self.sync.gbf, norm_partials=slots * hip.SUMSQ_PARTIALS)
         self.batches_seen += 1
         return total
 

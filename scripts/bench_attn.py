@@ -1,5 +1,6 @@
 """Attention fwd+bwd micro-benchmark at the MicroDiT-XL/2 shapes: python scripts/bench_attn.py [iters] [batch]
-bwd: the fused single launch (Sq, Skv <= 256) against the dQ + dK/dV kernel pair; algorithmic HBM bytes / time alongside."""
+bwd: the library's choice, the fused single launch in its single-phase and two-phase forms (the latter for Sq, Skv <= 96) and
+the dQ + dK/dV kernel pair; algorithmic HBM bytes / time alongside."""
 import os, sys, math
 from ctypes import byref
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,10 +31,13 @@ for name, B, H, Sq, Skv, packed in shapes:
                      Skv * ld[2], Sq * hid, 1 / math.sqrt(hd), hd, 0)
     st = hip.stream_ptr()
     elt = B * H * hd * 2
-    for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd      ", 4, 0, elt * (2 * Sq + 2 * Skv)), (L.md_attn_bwd, "bwd fused", 10, 0, elt * (4 * Sq + 4 * Skv)),
-                                        (L.md_attn_bwd, "bwd split", 10, 1, elt * (4 * Sq + 4 * Skv))):
+    for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd        ", 4, 0, elt * (2 * Sq + 2 * Skv)), (L.md_attn_bwd, "bwd auto   ", 10, 0, elt * (4 * Sq + 4 * Skv)),
+                                        (L.md_attn_bwd, "bwd 1-phase", 10, 2, elt * (4 * Sq + 4 * Skv)), (L.md_attn_bwd, "bwd 2-phase", 10, 3, elt * (4 * Sq + 4 * Skv)),
+                                        (L.md_attn_bwd, "bwd pair   ", 10, 1, elt * (4 * Sq + 4 * Skv))):
         a.bwd_split = split
-        fn(byref(a), st); torch.cuda.synchronize()
+        if fn(byref(a), st) == -1:
+            continue                      # a forced form that does not cover this shape
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters): fn(byref(a), st)

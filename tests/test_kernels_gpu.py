@@ -125,10 +125,12 @@ def _attn_ref(q, k, v, H, hd):
                                                     (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
                                                     (1, 2, 1024, 1024, 64, True), (2, 12, 256, 77, 64, False),
                                                     (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True)])
-@pytest.mark.parametrize("bwd_split", [0, 1])
+@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3])
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
-    kernel pair (the only path for longer sequences).  Both against torch fp32 autograd of the same bf16 inputs."""
+    kernel pair (the only path for longer sequences); 2 / 3: the fused backward forced to its single-phase (Q, dO, K, V in LDS
+    together; Sq, Skv <= 256) or two-phase (half the LDS image; Sq, Skv <= 96) form -- a forced form that does not cover the
+    problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
     L, st = hip.lib(), hip.stream_ptr()
     hid = H * hd
@@ -161,7 +163,14 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    hip.check(L.md_attn_bwd(byref(a), st), "attn bwd")
+    covered = {0: True, 1: True, 2: max(Sq, Skv) <= 256, 3: max(Sq, Skv) <= 96}[bwd_split]
+    rc = L.md_attn_bwd(byref(a), st)
+    if not covered:
+        torch.cuda.synchronize()
+        assert rc == -1, f"forced backward form {bwd_split} must refuse Sq={Sq} Skv={Skv} (rc {rc})"
+        assert float(dq.abs().max()) == 0.0 and float(dk.abs().max()) == 0.0, "a refused launch must not write"
+        return
+    hip.check(rc, "attn bwd")
     qr = q.float().clone().requires_grad_(True)
     kr = k.float().clone().requires_grad_(True)
     vr = v.float().clone().requires_grad_(True)
