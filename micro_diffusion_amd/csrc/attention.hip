@@ -599,8 +599,13 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
 //   P6  dK, dV (role 2).
 // LDS: 2 * max(SQP, SKP) * (HD + 8) * 2 bytes + lse / delta (18.9 KiB at 64 x 64, 28.2 KiB with 77 keys).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HD, int SQP, int SKP>
-__global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) __attribute__((amdgpu_waves_per_eu(3)))
+// SPLIT2 (the 256-row buckets, 8-wave workgroups): role 2 runs as two passes over the query tiles — dV from P alone, then dK
+// from dS — so that only ONE 32 x HD accumulator pair is alive at a time and the kernel fits 128 VGPRs: 16 wave slots per CU
+// hold two of those workgroups (75.8 KiB of LDS each), where the single-phase kernel (190 VGPRs, 149.5 KiB) holds one and has
+// nothing to overlap its load and store phases with.  Price: S = Q K^T and the exponentials of role 2 are formed twice
+// (20 instead of 16 MFMAs per tile pair).
+template <int HD, int SQP, int SKP, bool SPLIT2>
+__global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) __attribute__((amdgpu_waves_per_eu(SPLIT2 ? 4 : 3)))
 void attn_bwd_fused2_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     constexpr int RMAX = SQP > SKP ? SQP : SKP;
@@ -754,55 +759,126 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
     // ---- P6 role 2: dK, dV for key rows wave * 32 ..
     if (krole) {
         const int64_t key = (int64_t)wave * 32 + (lane & 31);
-        f32x16 dkacc[HD / 32], dvacc[HD / 32];
+        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
+        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+        if (SPLIT2) {
+            f32x16 acc[HD / 32];
+            // pass 1: dV = P^T dO
 #pragma unroll
-        for (int di = 0; di < HD / 32; ++di)
+            for (int di = 0; di < HD / 32; ++di)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dkacc[di][r] = 0.f;
-                dvacc[di][r] = 0.f;
-            }
-        for (int i = 0; i < nq32; ++i) {
-            const unsigned char* tQ = sA + i * 32 * PK;
-            const unsigned char* tdO = sB + i * 32 * PK;
-            const float* tLse = sLse + i * 32;
-            const float* tDlt = sDlt + i * 32;
-            f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+                for (int r = 0; r < 16; ++r) acc[di][r] = 0.f;
+            for (int i = 0; i < nq32; ++i) {
+                const unsigned char* tQ = sA + i * 32 * PK;
+                const unsigned char* tdO = sB + i * 32 * PK;
+                const float* tLse = sLse + i * 32;
+                f32x16 sacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[r] = 0.f;
-                dpacc[r] = 0.f;
-            }
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < HD / 16; ++s) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
-                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
-            }
+                for (int s = 0; s < HD / 16; ++s)
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
-                sacc[r] = pr;                                           // P
-                dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    sacc[r] = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;   // P
+                }
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 pf = pack8(sacc, 8 * sp);
-                const bf16x8 dsf = pack8(dpacc, 8 * sp);
+                for (int sp = 0; sp < 2; ++sp) {
+                    const bf16x8 pf = pack8(sacc, 8 * sp);
 #pragma unroll
-                for (int di = 0; di < HD / 32; ++di) {
-                    dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
-                    dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+                    for (int di = 0; di < HD / 32; ++di)
+                        acc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, acc[di], 0, 0, 0);
                 }
             }
-        }
-        if (key < p.Skv) {
-            bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
-            bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
-            store_rows<HD>(dK, dkacc, 1.f, lane);
-            store_rows<HD>(dV, dvacc, 1.f, lane);
+            if (key < p.Skv) store_rows<HD>(dV, acc, 1.f, lane);
+            // pass 2: dK = dS^T Q
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[di][r] = 0.f;
+            for (int i = 0; i < nq32; ++i) {
+                const unsigned char* tQ = sA + i * 32 * PK;
+                const unsigned char* tdO = sB + i * 32 * PK;
+                const float* tLse = sLse + i * 32;
+                const float* tDlt = sDlt + i * 32;
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = 0.f;
+                    dpacc[r] = 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < HD / 16; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
+                    dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
+                }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+                    for (int di = 0; di < HD / 32; ++di)
+                        acc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, acc[di], 0, 0, 0);
+                }
+            }
+            if (key < p.Skv) store_rows<HD>(dK, acc, 1.f, lane);
+        } else {
+            f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dkacc[di][r] = 0.f;
+                    dvacc[di][r] = 0.f;
+                }
+            for (int i = 0; i < nq32; ++i) {
+                const unsigned char* tQ = sA + i * 32 * PK;
+                const unsigned char* tdO = sB + i * 32 * PK;
+                const float* tLse = sLse + i * 32;
+                const float* tDlt = sDlt + i * 32;
+                f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = 0.f;
+                    dpacc[r] = 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < HD / 16; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
+                    sacc[r] = pr;                                           // P
+                    dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
+                }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const bf16x8 pf = pack8(sacc, 8 * sp);
+                    const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+                    for (int di = 0; di < HD / 32; ++di) {
+                        dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
+                        dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+                    }
+                }
+            }
+            if (key < p.Skv) {
+                store_rows<HD>(dK, dkacc, 1.f, lane);
+                store_rows<HD>(dV, dvacc, 1.f, lane);
+            }
         }
     }
 }
@@ -810,33 +886,31 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
 // Padded row-count bucket of the fused backward: 64, 96 or 256 (0 = not covered)
 inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 256 ? 256 : 0; }
 
-// variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image (row counts <= 96 only),
-// 0 = the rule: two-phase where it exists (it doubles the resident workgroups of the backbone shapes), single-phase for the
-// 256-row buckets (8-wave workgroups: the register budget, not LDS, holds those at one workgroup per CU either way).
+// variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image, 0 = the rule: two-phase for row counts
+// <= 96 (it holds 1.5-2x the workgroups per CU) AND for the 256-row buckets (its SPLIT2 form: two workgroups per CU
+// instead of one).
 template <int HD>
 bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
     if (!bq || !bk) return false;
-    const bool small = bq <= 96 && bk <= 96;
-    if (variant == 3 && !small) return false;
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-#define FUSED2(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-    if (small && variant != 2) {
-        if (bq == 64 && bk == 64) FUSED2(64, 64);
-        else if (bq == 64 && bk == 96) FUSED2(64, 96);
-        else if (bq == 96 && bk == 64) FUSED2(96, 64);
-        else FUSED2(96, 96);
-    }
-    else if (bq == 64 && bk == 64) FUSED(64, 64);
-    else if (bq == 64 && bk == 96) FUSED(64, 96);
-    else if (bq == 96 && bk == 64) FUSED(96, 64);
-    else if (bq == 96 && bk == 96) FUSED(96, 96);
-    else if (bq == 256 && bk == 96) FUSED(256, 96);
-    else if (bq == 256 && bk == 256) FUSED(256, 256);
-    else if (bq == 64 && bk == 256) FUSED(64, 256);
-    else if (bq == 256 && bk == 64) FUSED(256, 64);
-    else FUSED(96, 256);
+#define FUSED2(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, (SQP > 96 || SKP > 96)>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
+#define BOTH(SQP, SKP)                   \
+    do {                                 \
+        if (variant == 2) FUSED(SQP, SKP); \
+        else FUSED2(SQP, SKP);           \
+    } while (0)
+    if (bq == 64 && bk == 64) BOTH(64, 64);
+    else if (bq == 64 && bk == 96) BOTH(64, 96);
+    else if (bq == 96 && bk == 64) BOTH(96, 64);
+    else if (bq == 96 && bk == 96) BOTH(96, 96);
+    else if (bq == 256 && bk == 96) BOTH(256, 96);
+    else if (bq == 256 && bk == 256) BOTH(256, 256);
+    else if (bq == 64 && bk == 256) BOTH(64, 256);
+    else if (bq == 256 && bk == 64) BOTH(256, 64);
+    else BOTH(96, 256);
+#undef BOTH
 #undef FUSED
 #undef FUSED2
     return true;

@@ -218,28 +218,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
         if (GENERIC) load_row<NCH, GENERIC, GENERIC>(p, row, lane, v, raw);
         else unpack_row<NCH>(nx, v);
         const float mean = nmean, rstd = nrstd;
-        float g[NCH][8];  // dL/dxhat
+        // dL/dxhat = dz * wm is formed twice (here for the two row sums, below for dx) from the PACKED dz kept in dzk: half the
+        // registers of an fp32 copy, which is what takes the NCH = 2 kernel from 134 to under 128 VGPRs (4 waves / SIMD)
+        bf16x8 dzk[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane * 8 + j * 512;
+            dzk[j] = nz[j];
             if (c < p.C) {
-                const bf16x8 dzv = nz[j];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float dz = bf2f(dzv[e]);
+                    const float dz = bf2f(dzk[j][e]);
                     const float xh = (v[j][e] - mean) * rstd;
                     v[j][e] = xh;
                     accS[j][e] += dz * xh;
                     accD[j][e] += dz;
                     const float gg = dz * wm[j][e];
-                    g[j][e] = gg;
                     s1 += gg;
                     s2 += gg * xh;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[j][e] = 0.f;
             }
         }
         if (lr + 1 < r1) {    // the next row's loads fly during this row's reductions and dx pass (nx / nz are consumed: no extra registers)
@@ -261,7 +259,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(md_ln_args p, md_ln_bwd_arg
                     if (b.accumulate) prev = ld_bf16x8(dxr + c);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float d = rstd * (g[j][e] - s1 - v[j][e] * s2);
+                        float d = rstd * (bf2f(dzk[j][e]) * wm[j][e] - s1 - v[j][e] * s2);
                         if (GENERIC && p.act) d *= act_bwd(raw[j][e], p.act);
                         if (b.accumulate) d += bf2f(prev[e]);
                         o[e] = f2bf(d);

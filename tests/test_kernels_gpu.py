@@ -129,8 +129,9 @@ def _attn_ref(q, k, v, H, hd):
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
     kernel pair (the only path for longer sequences); 2 / 3: the fused backward forced to its single-phase (Q, dO, K, V in LDS
-    together; Sq, Skv <= 256) or two-phase (half the LDS image; Sq, Skv <= 96) form -- a forced form that does not cover the
-    problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of the same bf16 inputs."""
+    together) or two-phase (half the LDS image; role 2 in two passes for the 256-row buckets) form, both for Sq, Skv <= 256 --
+    a forced form that does not cover the problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of
+    the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
     L, st = hip.lib(), hip.stream_ptr()
     hid = H * hd
@@ -163,7 +164,7 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    covered = {0: True, 1: True, 2: max(Sq, Skv) <= 256, 3: max(Sq, Skv) <= 96}[bwd_split]
+    covered = {0: True, 1: True, 2: max(Sq, Skv) <= 256, 3: max(Sq, Skv) <= 256}[bwd_split]
     rc = L.md_attn_bwd(byref(a), st)
     if not covered:
         torch.cuda.synchronize()
