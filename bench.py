@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-other-stages", action="store_true", help="skip the res_256_finetune / res_512_pretrain / microbatch-256 legs")
+    ap.add_argument("--attn-bwd", default="auto", choices=["auto", "pair", "fused1", "fused2", "fused2s"],
+                    help="A/B runs: force one attention-backward kernel wherever it covers the shape (default: the library's rule)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -221,6 +223,8 @@ def main():
             dist.init_process_group(backend)
 
     head = Stage("res_256_pretrain", args.arch, args.global_batch, args.microbatch, world, rank)
+    if args.attn_bwd != "auto":
+        head.model.dit.engine.attn_bwd_prefer = {"pair": 1, "fused1": 2, "fused2": 3, "fused2s": 4}[args.attn_bwd]
     elapsed, loss = head.timed(args.steps, args.warmup, world)
     ms_per_step = elapsed / args.steps * 1e3
     value = args.global_batch * args.steps / elapsed
@@ -240,6 +244,8 @@ def main():
         "step_mfma_frac": value / world * gf / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS,
     }
 
+    if args.attn_bwd != "auto":
+        out["config"]["attn_bwd_forced"] = args.attn_bwd
     if rank == 0 and not args.no_profile:
         # ---- roofline leg: per-launch HIP events around every launch of the dominant kernel (the MFMA GEMM) in one
         # extra, untimed step (events are recorded on the stream the kernels are launched on).

@@ -886,31 +886,37 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
 // Padded row-count bucket of the fused backward: 64, 96 or 256 (0 = not covered)
 inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 256 ? 256 : 0; }
 
-// variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image, 0 = the rule: two-phase for row counts
-// <= 96 (it holds 1.5-2x the workgroups per CU) AND for the 256-row buckets (its SPLIT2 form: two workgroups per CU
-// instead of one).
+// variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image (SPLIT2 for the 256-row buckets only),
+// 4 = two-phase with SPLIT2 everywhere (128 VGPRs for every bucket), 0 = the rule: 3.
 template <int HD>
 bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
     if (!bq || !bk) return false;
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-#define FUSED2(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, (SQP > 96 || SKP > 96)>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-#define BOTH(SQP, SKP)                   \
-    do {                                 \
-        if (variant == 2) FUSED(SQP, SKP); \
-        else FUSED2(SQP, SKP);           \
+#define FUSED2(SQP, SKP, SPL) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
+#define SMALL(SQP, SKP)                          \
+    do {                                         \
+        if (variant == 2) FUSED(SQP, SKP);       \
+        else if (variant == 4) FUSED2(SQP, SKP, true); \
+        else FUSED2(SQP, SKP, false);            \
     } while (0)
-    if (bq == 64 && bk == 64) BOTH(64, 64);
-    else if (bq == 64 && bk == 96) BOTH(64, 96);
-    else if (bq == 96 && bk == 64) BOTH(96, 64);
-    else if (bq == 96 && bk == 96) BOTH(96, 96);
-    else if (bq == 256 && bk == 96) BOTH(256, 96);
-    else if (bq == 256 && bk == 256) BOTH(256, 256);
-    else if (bq == 64 && bk == 256) BOTH(64, 256);
-    else if (bq == 256 && bk == 64) BOTH(256, 64);
-    else BOTH(96, 256);
-#undef BOTH
+#define BIG(SQP, SKP)                            \
+    do {                                         \
+        if (variant == 2) FUSED(SQP, SKP);       \
+        else FUSED2(SQP, SKP, true);             \
+    } while (0)
+    if (bq == 64 && bk == 64) SMALL(64, 64);
+    else if (bq == 64 && bk == 96) SMALL(64, 96);
+    else if (bq == 96 && bk == 64) SMALL(96, 64);
+    else if (bq == 96 && bk == 96) SMALL(96, 96);
+    else if (bq == 256 && bk == 96) BIG(256, 96);
+    else if (bq == 256 && bk == 256) BIG(256, 256);
+    else if (bq == 64 && bk == 256) BIG(64, 256);
+    else if (bq == 256 && bk == 64) BIG(256, 64);
+    else BIG(96, 256);
+#undef SMALL
+#undef BIG
 #undef FUSED
 #undef FUSED2
     return true;
@@ -952,7 +958,7 @@ extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
     // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
-    if (a->bwd_split < 0 || a->bwd_split > 3) return MD_BAD_ARG;
+    if (a->bwd_split < 0 || a->bwd_split > 4) return MD_BAD_ARG;
     if (a->bwd_split != 1) {
         if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
             MD_LAUNCH_CHECK();

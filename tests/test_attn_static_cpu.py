@@ -64,6 +64,9 @@ def test_attention_kernel_resources(tmp_path):
             hits = [k for k in res if f"attn_bwd_fused2_kernelILi{hd}ELi{sqp}ELi{skp}ELb{int(split2)}EE" in k]
             assert len(hits) == 1, (hd, sqp, skp, hits)
             two, one = res[hits[0]], find("attn_bwd_fused_kernel", hd, sqp, skp)
+            if not split2:       # the two-pass form is also built for the small buckets (forced variant 4): 4 waves / SIMD as well
+                alt = [k for k in res if f"attn_bwd_fused2_kernelILi{hd}ELi{sqp}ELi{skp}ELb1EE" in k]
+                assert len(alt) == 1 and res[alt[0]]["occ"] >= 4 and res[alt[0]]["lds"] == two["lds"], (hd, sqp, skp, alt)
             assert two["lds"] == _lds_2phase(hd, sqp, skp) and one["lds"] == _lds_1phase(hd, sqp, skp), (hd, sqp, skp, two, one)
             assert two["occ"] >= (4 if (split2 or hd == 32) else 3), (hd, sqp, skp, two)
             # resident workgroups per CU (LDS 160 KiB, 4 SIMDs): the reason the kernel exists

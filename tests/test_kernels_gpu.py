@@ -125,11 +125,12 @@ def _attn_ref(q, k, v, H, hd):
                                                     (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
                                                     (1, 2, 1024, 1024, 64, True), (2, 12, 256, 77, 64, False),
                                                     (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True)])
-@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3])
+@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4])
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
-    kernel pair (the only path for longer sequences); 2 / 3: the fused backward forced to its single-phase (Q, dO, K, V in LDS
-    together) or two-phase (half the LDS image; role 2 in two passes for the 256-row buckets) form, both for Sq, Skv <= 256 --
+    kernel pair (the only path for longer sequences); 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in
+    LDS together) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4)) form, all
+    for Sq, Skv <= 256 --
     a forced form that does not cover the problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of
     the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
@@ -164,7 +165,7 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    covered = {0: True, 1: True, 2: max(Sq, Skv) <= 256, 3: max(Sq, Skv) <= 256}[bwd_split]
+    covered = bwd_split in (0, 1) or max(Sq, Skv) <= 256
     rc = L.md_attn_bwd(byref(a), st)
     if not covered:
         torch.cuda.synchronize()
