@@ -111,11 +111,11 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
         }
 }
 
-// Register budget: with up to two staging chunks per thread the kernel fits 128 VGPRs without spilling (117 at head_dim 64), i.e.
-// 4 waves / SIMD instead of the 3 the unconstrained allocation (136) allows; workgroups here are 2-4 waves of serial
-// load -> MFMA -> softmax chains, so resident waves are what hides their latency.
+// (Measured and dropped: capping this kernel at 128 VGPRs -- 117 without a spill at head_dim 64, 4 waves / SIMD instead of 3 --
+// made the 2-wave instantiation 15 % SLOWER in the step, 142.7 -> 164.9 us; the allocation the compiler picks on its own keeps
+// more of a phase's loads in flight.  profiles/r2_attention_two_phase_bwd.txt.)
 template <int HD, int MAXIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXIT <= 2 ? 4 : 1))) void attn_fwd_kernel(md_attn_args p) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
@@ -887,7 +887,10 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
 inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 256 ? 256 : 0; }
 
 // variant: 2 = single-phase image (Q, dO, K, V in LDS together), 3 = two-phase image (SPLIT2 for the 256-row buckets only),
-// 4 = two-phase with SPLIT2 everywhere (128 VGPRs for every bucket), 0 = the rule: 3.
+// 4 = two-phase with SPLIT2 everywhere (128 VGPRs for every bucket), 0 = the measured rule (MI355X, batch 1024,
+// profiles/r2_attention_two_phase_bwd.txt): two-phase everywhere (-9 % with 77 keys, -10 % / -18 % on the 256-row buckets) except
+// the 64 x 64 bucket pair, where the single-phase kernel is 10 % ahead (two-wave workgroups: the five extra barriers cost more
+// than 6 instead of 4 resident workgroups return).
 template <int HD>
 bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
@@ -897,7 +900,7 @@ bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
 #define FUSED2(SQP, SKP, SPL) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
 #define SMALL(SQP, SKP)                          \
     do {                                         \
-        if (variant == 2) FUSED(SQP, SKP);       \
+        if (variant == 2 || (variant == 0 && SQP == 64 && SKP == 64)) FUSED(SQP, SKP); \
         else if (variant == 4) FUSED2(SQP, SKP, true); \
         else FUSED2(SQP, SKP, false);            \
     } while (0)

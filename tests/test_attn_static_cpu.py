@@ -77,8 +77,6 @@ def test_attention_kernel_resources(tmp_path):
                 assert wg2 > wg1, f"hd {hd} {sqp}x{skp}: two-phase holds {wg2} workgroups per CU, single-phase {wg1}"
             else:
                 assert wg2 >= wg1
-    # forward: the 2-4 wave workgroups of the training shapes at 4 waves / SIMD
-    assert find("attn_fwd_kernel", 64, 2)["occ"] >= 4 and find("attn_fwd_kernel", 64, 1)["occ"] >= 4
 
 
 # ---------------------------------------------------------------------------------------- host model of the LDS image
