@@ -11,7 +11,13 @@ Extra keys of the line (the headline fields are unchanged by them):
                  1 warm-up + 2 timed steps each, N = 1 only (--no-other-stages skips them);
   value_mb256    the headline step with the YAML microbatch (256 = the per-rank shape of an 8-GPU run), N = 1 only;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
-                 the committed rocprofv3 PMC pass (profiles/r2_gemm_traffic.json; null when that file is absent);
+                 the committed rocprofv3 PMC passes (profiles/r3_gemm_traffic.json: counters need rocprofv3 around the process,
+                 so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
+                 the library it was measured on and `traffic` is null when that differs from the running build);
+  roofline_hbm   the three largest bandwidth-bound kernel classes (LayerNorm, attention, QK-LayerNorm): algorithmic bytes /
+                 per-launch HIP-event time against the 8 TB/s HBM3E peak, from the same untimed profiling step;
+  dp             (N > 1) ranks verified by an all-reduce of ones over RCCL, exchange format, buckets, and the time the
+                 compute stream waited for the gradient exchange after the last backward kernel (`exposed_comm_ms`);
   cpu_baseline   the CPU restatement of the reference step on the host cores (kind "port": the reference is pure Python and
                  /root/reference does not travel to the GPU box), >= 3 timed steps, threads used and host cores stated.
 """
@@ -54,6 +60,7 @@ def dezero_(dit, seed=1234):
                 p.add_(torch.randn(p.shape, device=p.device, generator=g) * 0.02)
 
 
+HBM_PEAK_TBS = 8.0                  # /opt/skills/guides/MI355X_MICROARCH.md (HBM3E)
 CPU_BASELINE_THREADS_CAP = 32      # torch CPU ops with hundreds of threads on small tensors oversubscribe badly
 CPU_BASELINE_TIMEOUT_S = 300
 CPU_BASELINE_STEPS = 3             # timed steps after one warm-up
@@ -87,7 +94,8 @@ def _cpu_baseline_worker():
                 sd[k].grad = None
         times.append(time.time() - ts)
     per = sum(times[1:]) / len(times[1:])          # first step = warm-up
-    print(json.dumps({"value": B / per, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+    print(json.dumps({"value": B / per, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(),
+                      "cores_note": f"{threads} threads (cap {CPU_BASELINE_THREADS_CAP}) of {os.cpu_count()} host cores", "kind": "port",
                       "sample": f"oracle/microdit_ref.py (CPU fp32 restatement of the reference step: LatentDiffusion.forward + backward + "
                                 f"clip_grad_norm_ + AdamW, pinned to the reference by tests/golden/xl2_mask75.npz) MicroDiT-XL/2 mask=0.75, "
                                 f"batch {B}, {len(times) - 1} timed steps after 1 warm-up, {per:.2f} s/step, torch.set_num_threads({threads}) "
@@ -140,11 +148,9 @@ class Stage:
             "caption_latents": torch.randn(per_rank, 1, 77, 1024, device="cuda", generator=g).half(),
             "drop_caption_mask": (torch.rand(per_rank, device="cuda", generator=g) >= 0.1).float(),
         }
-        self.caps = self.batch["caption_latents"].clone()
 
     def step(self):
-        self.batch["caption_latents"].copy_(self.caps)   # forward() zeroes dropped captions in place, like the reference
-        return self.trainer.train_step(self.batch)
+        return self.trainer.train_step(self.batch)       # the caption-drop mask is applied inside the first kernel, not in place
 
     def timed(self, steps, warmup, world):
         for _ in range(warmup):
@@ -169,7 +175,7 @@ class Stage:
         return elapsed, float(loss.item())
 
     def close(self):
-        self.model = self.trainer = self.batch = self.caps = None
+        self.model = self.trainer = self.batch = None
         gc.collect()
         torch.cuda.empty_cache()
 
@@ -215,14 +221,34 @@ def main():
     # MD_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the distributed path on a 1-GPU box)
     backend = os.environ.get("MD_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank % ndev)
+    dp = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
+            if ndev < world:
+                raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, found {ndev} "
+                                 "(MD_DIST_BACKEND=gloo runs a functional test of several ranks on one GPU)")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
         else:
             dist.init_process_group(backend)
+        if dist.get_backend() != backend:
+            raise SystemExit(f"process group came up on '{dist.get_backend()}', not '{backend}'")
+        # every rank really is on the wire: an all-reduce of ones must count them
+        ones = torch.ones(1, device="cuda")
+        if backend == "nccl":
+            dist.all_reduce(ones)
+        else:
+            h = ones.cpu()
+            dist.all_reduce(h)
+            ones = h
+        counted = int(ones.item())
+        if counted != world:
+            raise SystemExit(f"all-reduce of ones returned {counted}, expected {world} ranks")
+        dp = {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "rccl_ranks": counted if backend == "nccl" else 0,
+              "ranks": counted, "devices_visible": ndev}
 
     head = Stage("res_256_pretrain", args.arch, args.global_batch, args.microbatch, world, rank)
+    head.trainer.measure_comm = world > 1
     if args.attn_bwd != "auto":
         head.model.dit.engine.attn_bwd_prefer = {"pair": 1, "fused1": 2, "fused2": 3, "fused2s": 4}[args.attn_bwd]
     elapsed, loss = head.timed(args.steps, args.warmup, world)
@@ -243,6 +269,15 @@ def main():
         "loss": loss,
         "step_mfma_frac": value / world * gf / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS,
     }
+    if dp is not None:
+        sync = head.trainer.sync
+        ex = head.trainer.exposed_comm_ms(last=args.steps)
+        dp.update(exchange_dtype=sync.exchange, buckets=sync.last_buckets, bytes_per_step=sync.last_bytes,
+                  exposed_comm_ms=ex, exposed_comm_share=(ex / ms_per_step if ex is not None else None),
+                  note="exposed_comm_ms = time the compute stream waited for the gradient exchange (and the side-stream bucket "
+                       "norms) after the last backward kernel, mean over the timed steps of rank 0; criterion for moving the "
+                       "exchange into an md_comm_* C ABI with reduce-scatter + all-gather over all 7 xGMI links: > 10 ms at N = 8")
+        out["dp"] = dp
 
     if args.attn_bwd != "auto":
         out["config"]["attn_bwd_forced"] = args.attn_bwd
@@ -251,11 +286,13 @@ def main():
         # extra, untimed step (events are recorded on the stream the kernels are launched on).
         eng = head.model.dit.engine
         eng.gemm_profile = []
+        eng.kernel_profile = {}
         if world == 1:
             head.step()
         else:   # profile a single microbatch locally, without collectives
             part = {k: v[:head.microbatch] for k, v in head.batch.items()}
-            head.model(part)[0].backward()
+            head.trainer.sync.active = False
+            head.model.train_microbatch(part)
         torch.cuda.synchronize()
         prof, eng.gemm_profile = eng.gemm_profile, None
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
@@ -271,7 +308,18 @@ def main():
                            "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None,
                            "algorithmic_bytes_per_launch": tot_by / n,
                            "traffic_over_algorithmic": (traffic / (tot_by / n)) if traffic else None,
-                           "traffic_source": ({k: v for k, v in tinfo.items() if k != "per_kernel"} if tinfo else None)}
+                           "traffic_measured_in_run": False, "traffic_source": tinfo}
+        # ---- HBM side: the largest bandwidth-bound kernel classes of the same profiling step
+        hb = {}
+        for name, recs in (eng.kernel_profile or {}).items():
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            byt = sum(r[2] for r in recs)
+            if ms > 0:
+                hb[name] = {"launches": len(recs), "total_ms": ms, "algorithmic_gb": byt / 1e9, "achieved_tbs": byt / (ms * 1e-3) / 1e12,
+                            "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                            "share_of_step": (ms / ms_per_step) if world == 1 else None}
+        eng.kernel_profile = None
+        out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_TBS, "unit": "TB/s", "kernels": dict(sorted(hb.items(), key=lambda kv: -kv[1]["total_ms"]))}
     if world == 1 and not args.no_other_stages:
         # ---- the YAML microbatch (the per-rank shape of an 8-GPU run) on the same model
         head.trainer.microbatch_size = 256

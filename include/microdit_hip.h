@@ -70,11 +70,20 @@ typedef struct md_gemm_args {
     void* timeline;         /* profiling aid, normally NULL: every workgroup of the 2-stage kernels writes 8 int64
                                {t_entry, t_prologue_done, t_loop_done, t_stores_drained (shader clock), wall clock
                                (100 MHz), XCC_ID << 32 | HW_ID, 0, 0} at timeline[linear_workgroup_id * 8] */
+    int32_t* chosen_variant; /* optional HOST pointer: receives the md_gemm_variant that was actually launched */
+    /* Operand lists (PP256 only; NULL = the strided form above).  DEVICE arrays of batch * ksplit device pointers: item
+     * (batch b, split s) reads A_list[b * ksplit + s] / B_list[b * ksplit + s] as ITS operand for a contraction of length
+     * K / ksplit starting at element 0 -- i.e. a "split" is then a separate operand pair whose products are summed by
+     * md_splitk_reduce (the adaLN condition-vector gradient: sum over 28 layers of dmod_l W_l in ONE launch), and a "batch"
+     * a separate problem of the same shape. */
+    const void* const* A_list;
+    const void* const* B_list;
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot
  * run the requested problem (PP256 needs K / ksplit to be a multiple of 128, N a multiple of 8, no atomics) is
- * rejected with -1 rather than silently replaced. */
+ * rejected with MD_NOT_ELIGIBLE (-2; nothing was launched) rather than silently replaced; a malformed problem is -1. */
+#define MD_NOT_ELIGIBLE (-2)
 enum md_gemm_variant {
     MD_GEMM_AUTO = 0,
     MD_GEMM_REG128 = 1,   /* 128 x 128 tile, register-staged global -> LDS, 3 workgroups / CU                        */
@@ -203,6 +212,11 @@ int md_moe_dispatch_bwd(const void* dxin, const int32_t* slot, void* dx, const f
 /* ------------------------------------------------------------------------------------------- EDM front / back end */
 int md_edm_prepare(const float* x0, const float* eps, const float* rnd, float* xn, float* sigma, float* cin, float* cnoise,
                    int64_t B, int64_t per_sample, float p_mean, float p_std, float sigma_data, hipStream_t stream);
+/* The same for the fp16 latents the precomputed-latent datasets hold (datasets/latents_loader.py:55-66): also writes the
+ * fp32 copy of the clean latents the loss reads, so no torch cast runs on the step path. */
+int md_edm_prepare_f16(const void* x0_f16, const float* eps, const float* rnd, float* xn, float* x0_f32, float* sigma, float* cin,
+                       float* cnoise, int64_t B, int64_t per_sample, float p_mean, float p_std, float sigma_data,
+                       hipStream_t stream);
 int md_patchify(const float* x, const float* scale, void* out, int64_t B, int32_t C, int32_t H, int32_t W, int32_t p,
                 hipStream_t stream);
 int md_timestep_embed(const float* t, void* out, int64_t B, int32_t dim, hipStream_t stream);
@@ -212,6 +226,14 @@ int md_unpatchify(const void* tok, const int32_t* ids_restore, int64_t Tk, const
 int md_edm_loss(const void* tok, const int32_t* keep_rows, const float* xn, const float* x0, const float* sigma,
                 float* loss_per_sample, float* loss_mean, float* dtok, int64_t B, int64_t Tk, int32_t C, int32_t H, int32_t W,
                 int32_t p, float sigma_data, hipStream_t stream);
+/* The form one microbatch of a training step uses (replaces `(loss * n_micro / n_rank).backward()` of Composer's microbatch
+ * loop around model.py:104-142 and the scalar torch ops that come with it): dtok is written as bf16 (what the hand-written
+ * backward starts from) and pre-multiplied by grad_scale (the microbatch weight); loss_accum (optional) += accum_weight *
+ * batch-mean loss, so the rank-mean loss of the step accumulates on the device. */
+int md_edm_loss_train(const void* tok, const int32_t* keep_rows, const float* xn, const float* x0, const float* sigma,
+                      float* loss_per_sample, float* loss_mean, void* dtok_bf16, float grad_scale, float* loss_accum,
+                      float accum_weight, int64_t B, int64_t Tk, int32_t C, int32_t H, int32_t W, int32_t p, float sigma_data,
+                      hipStream_t stream);
 
 /* Sampler (model.py:231-297): the arithmetic around each network evaluation of the Heun loop, fused; fp64 state, fp32
  * preconditioning (model.py:144-179) and classifier-free-guidance combine (dit.py:542-550: F = [cond; uncond] halves). */

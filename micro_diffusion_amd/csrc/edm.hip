@@ -12,14 +12,17 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void edm_prepare_kernel(const float* x0, const float* eps, const float* rnd, float* xn,
-                                                          float* sigma, float* cin, float* cnoise, int64_t B,
+template <typename XT>
+__global__ __launch_bounds__(256) void edm_prepare_kernel(const XT* x0, const float* eps, const float* rnd, float* xn,
+                                                          float* x0_f32, float* sigma, float* cin, float* cnoise, int64_t B,
                                                           int64_t per, float p_mean, float p_std, float sd) {
     const int64_t total = B * per;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / per;
         const float s = expf(rnd[b] * p_std + p_mean);
-        xn[i] = x0[i] + eps[i] * s;
+        const float x = (float)x0[i];
+        xn[i] = x + eps[i] * s;
+        if (x0_f32) x0_f32[i] = x;      // the loss reads the clean latents as fp32 (model.py:104-110 casts the fp16 batch once)
         if (i % per == 0) {
             sigma[b] = s;
             cin[b] = 1.f / sqrtf(sd * sd + s * s);
@@ -82,10 +85,13 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const bf16* tok, const 
 
 // One workgroup per sample.  Kept token j of sample b sits at grid position keep_rows[b*Tk + j] - b*T (or j when
 // keep_rows is NULL = no masking).  loss_b = mean over kept patches of mean_{c,ph,pw} w * (D - x0)^2;
-// dtok = d(mean_b loss_b)/dF for the kept tokens (f32, [B*Tk, C*p*p], (ph, pw, c) order).
+// dtok = gscale * d(mean_b loss_b)/dF for the kept tokens ([B*Tk, C*p*p], (ph, pw, c) order; f32, or bf16 for the
+// training step, whose backward starts from bf16 anyway).  The batch mean is taken by edm_loss_finish_kernel in sample
+// order (the first version added the per-sample terms with float atomics: the loss depended on the arrival order).
+template <typename DT>
 __global__ __launch_bounds__(256) void edm_loss_kernel(const bf16* tok, const int32_t* keep_rows, const float* xn,
                                                        const float* x0, const float* sigma, float* loss_per_sample,
-                                                       float* loss_mean, float* dtok, int64_t B, int64_t Tk, int C, int H,
+                                                       DT* dtok, float gscale, int64_t B, int64_t Tk, int C, int H,
                                                        int W, int p, float sd) {
     __shared__ float red[4];
     const int gh = H / p, gw = W / p, pv = C * p * p;
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const bf16* tok, const in
     const float cskip = sd * sd / (s * s + sd * sd);
     const float cout = s * sd / sqrtf(s * s + sd * sd);
     const float norm = 1.f / ((float)pv * (float)Tk);
+    const float gfac = 2.f * wgt * cout * norm / (float)B * gscale;
     float acc = 0.f;
     for (int64_t i = threadIdx.x; i < Tk * pv; i += 256) {
         const int64_t j = i / pv;
@@ -108,15 +115,28 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const bf16* tok, const in
         const float D = cskip * xn[pix] + cout * F;
         const float diff = D - x0[pix];
         acc += wgt * diff * diff;
-        if (dtok) dtok[(b * Tk + j) * pv + e] = 2.f * wgt * diff * cout * norm / (float)B;
+        if (dtok) {
+            if constexpr (sizeof(DT) == 4) dtok[(b * Tk + j) * pv + e] = gfac * diff;
+            else dtok[(b * Tk + j) * pv + e] = f2bf(gfac * diff);
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
+    if (threadIdx.x == 0) loss_per_sample[b] = (red[0] + red[1] + red[2] + red[3]) * norm;
+}
+
+// loss_mean = (1 / B) sum_b loss_per_sample[b] in a fixed order (one wave: lane-strided partial sums, then the wave
+// reduction); optionally loss_accum += accum_weight * loss_mean (the rank-mean loss of a microbatched step).
+__global__ __launch_bounds__(64) void edm_loss_finish_kernel(const float* loss_per_sample, float* loss_mean, float* loss_accum,
+                                                             float accum_weight, int64_t B) {
+    float acc = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 64) acc += loss_per_sample[b];
+    acc = wave_sum(acc);
     if (threadIdx.x == 0) {
-        const float lb = (red[0] + red[1] + red[2] + red[3]) * norm;
-        loss_per_sample[b] = lb;
-        unsafeAtomicAdd(loss_mean, lb / (float)B);
+        const float m = acc / (float)B;
+        *loss_mean = m;
+        if (loss_accum) *loss_accum += accum_weight * m;
     }
 }
 
@@ -177,8 +197,18 @@ extern "C" int md_edm_prepare(const float* x0, const float* eps, const float* rn
                               float* cnoise, int64_t B, int64_t per_sample, float p_mean, float p_std, float sigma_data,
                               hipStream_t st) {
     if (!x0 || !eps || !rnd || !xn || !sigma || !cin || !cnoise || B <= 0 || per_sample <= 0) return MD_BAD_ARG;
-    hipLaunchKernelGGL(edm_prepare_kernel, dim3(egrid(B * per_sample)), dim3(256), 0, st, x0, eps, rnd, xn, sigma, cin,
-                       cnoise, B, per_sample, p_mean, p_std, sigma_data);
+    hipLaunchKernelGGL(edm_prepare_kernel<float>, dim3(egrid(B * per_sample)), dim3(256), 0, st, x0, eps, rnd, xn, (float*)nullptr,
+                       sigma, cin, cnoise, B, per_sample, p_mean, p_std, sigma_data);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_edm_prepare_f16(const void* x0_f16, const float* eps, const float* rnd, float* xn, float* x0_f32, float* sigma,
+                                  float* cin, float* cnoise, int64_t B, int64_t per_sample, float p_mean, float p_std,
+                                  float sigma_data, hipStream_t st) {
+    if (!x0_f16 || !eps || !rnd || !xn || !x0_f32 || !sigma || !cin || !cnoise || B <= 0 || per_sample <= 0) return MD_BAD_ARG;
+    hipLaunchKernelGGL(edm_prepare_kernel<_Float16>, dim3(egrid(B * per_sample)), dim3(256), 0, st, (const _Float16*)x0_f16, eps,
+                       rnd, xn, x0_f32, sigma, cin, cnoise, B, per_sample, p_mean, p_std, sigma_data);
     MD_LAUNCH_CHECK();
     return 0;
 }
@@ -212,10 +242,22 @@ extern "C" int md_edm_loss(const void* tok, const int32_t* keep_rows, const floa
                            int32_t H, int32_t W, int32_t p, float sigma_data, hipStream_t st) {
     if (!tok || !xn || !x0 || !sigma || !loss_per_sample || !loss_mean || B <= 0 || Tk <= 0 || H % p || W % p)
         return MD_BAD_ARG;
-    hipError_t e = hipMemsetAsync(loss_mean, 0, sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(edm_loss_kernel, dim3((unsigned)B), dim3(256), 0, st, (const bf16*)tok, keep_rows, xn, x0, sigma,
-                       loss_per_sample, loss_mean, dtok, B, Tk, C, H, W, p, sigma_data);
+    hipLaunchKernelGGL(edm_loss_kernel<float>, dim3((unsigned)B), dim3(256), 0, st, (const bf16*)tok, keep_rows, xn, x0, sigma,
+                       loss_per_sample, dtok, 1.f, B, Tk, C, H, W, p, sigma_data);
+    hipLaunchKernelGGL(edm_loss_finish_kernel, dim3(1), dim3(64), 0, st, loss_per_sample, loss_mean, (float*)nullptr, 0.f, B);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_edm_loss_train(const void* tok, const int32_t* keep_rows, const float* xn, const float* x0, const float* sigma,
+                                 float* loss_per_sample, float* loss_mean, void* dtok_bf16, float grad_scale, float* loss_accum,
+                                 float accum_weight, int64_t B, int64_t Tk, int32_t C, int32_t H, int32_t W, int32_t p,
+                                 float sigma_data, hipStream_t st) {
+    if (!tok || !xn || !x0 || !sigma || !loss_per_sample || !loss_mean || !dtok_bf16 || B <= 0 || Tk <= 0 || H % p || W % p)
+        return MD_BAD_ARG;
+    hipLaunchKernelGGL(edm_loss_kernel<bf16>, dim3((unsigned)B), dim3(256), 0, st, (const bf16*)tok, keep_rows, xn, x0, sigma,
+                       loss_per_sample, (bf16*)dtok_bf16, grad_scale, B, Tk, C, H, W, p, sigma_data);
+    hipLaunchKernelGGL(edm_loss_finish_kernel, dim3(1), dim3(64), 0, st, loss_per_sample, loss_mean, loss_accum, accum_weight, B);
     MD_LAUNCH_CHECK();
     return 0;
 }

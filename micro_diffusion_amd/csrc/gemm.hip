@@ -610,7 +610,9 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
     int variant = a->variant;
     if (variant < MD_GEMM_AUTO || variant > MD_GEMM_PP256) return MD_BAD_ARG;
-    if (variant >= MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
+    if (variant >= MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_NOT_ELIGIBLE;
+    if ((a->A_list || a->B_list) && !(a->A_list && a->B_list && md_gemm_pp_eligible(a))) return MD_BAD_ARG;   // operand lists: PP256 only
+    if (a->A_list) variant = MD_GEMM_PP256;
     if (variant == MD_GEMM_AUTO) {
         if (md_gemm_pp_eligible(a) && tiles256 >= 192)
             variant = MD_GEMM_PP256;
@@ -634,6 +636,7 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
         if (g > ntn_) g = ntn_;
         a_copy.raster_group_n = (int)g;
     }
+    if (a->chosen_variant) *a->chosen_variant = variant;
     if (variant >= MD_GEMM_PP256) return md_gemm_pp_launch(a, stream);
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);

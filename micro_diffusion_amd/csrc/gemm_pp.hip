@@ -268,9 +268,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     auto stager_open = [&](int n) {                // point the stager at item ordinal n
         int m0, n0, batch, split;
         work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
-        const int64_t kbeg = (int64_t)split * w.kspan;
+        int64_t kbeg = (int64_t)split * w.kspan;
         const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
         const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+        if (EPI == PP_E_F32 && p.A_list) {         // operand lists (fp32-slice kernels only: the others are at their register budget): every (batch, split) item names its own operand pair (uniform -> s_load)
+            const int li = __builtin_amdgcn_readfirstlane(batch * w.ksplit + split);
+            Ab = reinterpret_cast<const bf16*>(p.A_list[li]);
+            Bb = reinterpret_cast<const bf16*>(p.B_list[li]);
+            kbeg = 0;
+        }
         sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)m0 * w.lda + kbeg : Ab + kbeg * w.lda + m0);
         sB = reinterpret_cast<const char*>(BKC ? Bb + (int64_t)n0 * w.ldb + kbeg : Bb + kbeg * w.ldb + n0);
         stage_offsets<AKC>(aofs, m0, w.M, w.lda, wave, lane);
@@ -545,6 +551,7 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     const int64_t kspan = a->K / a->ksplit;
     if (kspan < 128 || kspan % 128) return false;
     if (a->N % 8) return false;                                  // 16-byte column chunks everywhere
+    if ((a->A_list || a->B_list) && epi != PP_E_F32) return false;   // operand lists are built into the fp32-slice kernels only
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
     if ((epi == PP_E_RES || epi == PP_E_DACT_GELU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
         return false;                                            // only the PLAIN form of these two epilogues is built

@@ -31,13 +31,18 @@ from . import mds
 
 
 class SyntheticLatents:
-    """Endless iterator of device-resident synthetic batches: latents ~ N(0,1)*0.8, captions ~ N(0,1), captions
-    dropped with probability cap_drop_prob (the coin of latents_loader.py:49-51)."""
+    """Iterator of device-resident synthetic batches: latents ~ N(0,1)*0.8, captions ~ N(0,1), captions dropped with
+    probability cap_drop_prob (the coin of latents_loader.py:49-51).  loop=True (training): endless; loop=False (an
+    evaluation set): `length` samples = len(self) batches per pass, the same batches on every pass."""
 
     def __init__(self, batch_size: int, image_size: int = 256, cap_seq_size: int = 77, cap_emb_dim: int = 1024,
-                 cap_drop_prob: float = 0.0, in_channels: int = 4, device="cuda", seed: int = 2024, length: int = 1 << 30):
+                 cap_drop_prob: float = 0.0, in_channels: int = 4, device="cuda", seed: int = 2024, length: Optional[int] = None,
+                 loop: bool = True):
         self.bs, self.res = batch_size, image_size // 8
         self.L, self.D, self.p, self.C = cap_seq_size, cap_emb_dim, cap_drop_prob, in_channels
+        self.loop, self.seed = loop, seed
+        if length is None:
+            length = (1 << 30) if loop else 4 * batch_size
         self.device, self.length = device, length
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.dataset = range(length)
@@ -46,7 +51,11 @@ class SyntheticLatents:
         return self.length // self.bs
 
     def __iter__(self):
-        while True:
+        if not self.loop:
+            self.gen.manual_seed(self.seed)
+        n = 0
+        while self.loop or n < len(self):
+            n += 1
             g = self.gen
             yield {
                 "image_latents": (torch.randn(self.bs, self.C, self.res, self.res, device=self.device, generator=g) * 0.8).half(),
@@ -299,7 +308,8 @@ def build_streaming_latents_dataloader(datadir: Union[str, List[str]], batch_siz
     have = [d for d in dirs if os.path.isfile(os.path.join(d, "index.json"))]
     if not have and allow_synth:
         rank = int(os.environ.get("RANK", "0"))
-        return SyntheticLatents(batch_size, image_size, cap_seq_size, cap_emb_dim, cap_drop_prob, seed=2024 + rank)
+        return SyntheticLatents(batch_size, image_size, cap_seq_size, cap_emb_dim, cap_drop_prob, seed=2024 + rank,
+                                loop=bool(dataloader_kwargs.get("loop", True)))
     if len(have) != len(dirs) or not dirs:
         missing = sorted(set(dirs) - set(have))
         raise FileNotFoundError(f"MDS directories without index.json: {missing} (pass datadir='synthetic' for random latents)")

@@ -276,7 +276,7 @@ class _DiTFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: DiT, anchor, x, t, y, mask_ratio, mask_noise):
         eng = module._engine
-        tape = eng.forward(x, t, y, mask_ratio=mask_ratio, mask_noise=mask_noise)
+        tape = eng.forward(x, t, y, mask_ratio=mask_ratio, mask_noise=mask_noise, record_tape=True)
         ctx.module, ctx.tape = module, tape
         img = eng.sample_image(tape)
         mask = tape.mask

@@ -18,6 +18,7 @@ LayerNorm statistics, softmax, MoE routing and weight gradients (accumulated int
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from ctypes import byref
 from typing import Dict, List, Optional
@@ -38,25 +39,34 @@ class Tape:
 class _Arena:
     """Bump allocator over ONE device buffer.  With it the activations, gradients and scratch of a microbatch live at fixed
     addresses and the step path makes no allocator calls (no caching-allocator bookkeeping per launch, no at::native fill
-    kernels; the launch sequence of a microbatch becomes capturable as a hipGraph).  The first pass through a new shape runs
-    in measuring mode — plain torch.empty, sizes recorded with the same mark / release discipline — and the buffer is then
-    allocated once at the measured peak."""
+    kernels; the launch sequence of a microbatch becomes capturable as a hipGraph).  The first pass through a new shape key
+    runs in measuring mode — plain torch.empty, sizes recorded with the same mark / release discipline — and the buffer is
+    then (re)allocated at the largest peak of all keys seen, so alternating shapes (a ragged last microbatch) do not
+    re-measure.  A pass that raised is not recorded."""
     ALIGN = 256
 
     def __init__(self, dev):
         self.dev, self.buf, self.key = dev, None, None
+        self.peaks = {}                 # shape key -> measured peak bytes
         self.top = self.peak = 0
         self.measuring = True
 
     def begin(self, key):
-        if key != self.key:
-            self.key, self.buf, self.measuring, self.peak = key, None, True, 0
-        self.top = 0
+        self.key = key
+        need = self.peaks.get(key)
+        self.measuring = need is None or self.buf is None or self.buf.numel() < need + self.ALIGN
+        self.top = self.peak = 0
 
-    def end(self):
-        if self.measuring:
-            self.buf = torch.empty(self.peak + self.ALIGN, device=self.dev, dtype=torch.uint8)
-            self.measuring = False
+    def end(self, ok: bool = True):
+        if not self.measuring:
+            return
+        if not ok:                      # the pass raised half-way: its peak is not the shape's peak
+            return
+        self.peaks[self.key] = self.peak
+        need = max(self.peaks.values()) + self.ALIGN
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = None             # release before re-allocating
+            self.buf = torch.empty(need, device=self.dev, dtype=torch.uint8)
 
     def mark(self) -> int:
         return self.top
@@ -95,15 +105,25 @@ class DiTEngine:
         self.L = hip.lib()
         self.wgrad_target_blocks = 768
         self.gemm_profile = None
+        self.kernel_profile = None         # bench.py: {class name: [(event0, event1, algorithmic bytes)]} for the bandwidth-bound kernels
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
         self.attn_bwd_prefer = hip.ATTN_BWD_AUTO   # same for the attention backward (md_attn_args.bwd_split)
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
+        self.keep_last_tape = False        # tests: keep the most recent forward's tape in self.last_tape (per-block activations)
+        self.last_tape = None
+        self.route_override = None         # tests: {block name: top-k token indices [B, E, k]} replacing the router's choice
         self.ws = torch.empty(128 << 20, device=self.dev, dtype=F32)  # 512 MiB split-K workspace
         # Fixed-address activation memory (opt-in: the caller must run forward -> backward strictly in turn, as the Trainer
         # does; two forwards in flight would share the tape arena).
         self.use_arena = False
         self._tape_arena, self._scratch_arena = _Arena(self.dev), _Arena(self.dev)
         self._arena = None          # arena the next empty() / zeros() comes from (None = torch allocator)
+        self._record = False        # current forward keeps per-block tapes
+        self._chosen = ctypes.c_int32(-1)   # md_gemm_args.chosen_variant lands here
+        self._ptr_cache = {}
+        self.ksplit_min_items = 192  # work items a split-K factor must reach (A/B: 128 = the round-2 rule)
+        self.splitk_force_pp = False  # A/B: force pp256 for every split-K launch it accepts, whatever the tile count
+        self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
 
     # ------------------------------------------------------------------------------------------ launch helpers
@@ -120,6 +140,29 @@ class DiTEngine:
         hip.check(self.L.md_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._st()), "md_fill_zero")
         return t
 
+    def _prof(self, name, nbytes, launch):
+        """Run `launch()`; with kernel_profile set, bracket it with HIP events on the launch stream (bench.py roofline_hbm leg)."""
+        kp = self.kernel_profile
+        if kp is None:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        kp.setdefault(name, []).append((e0, e1, float(nbytes)))
+
+    def _qkln_fwd(self, ptr, rows, ld, off, width, rstd_ptr):
+        self._prof("qk_layernorm", 4.0 * rows * width, lambda: hip.check(
+            self.L.md_qkln_fwd(ptr, rows, ld, off, width, rstd_ptr, self.cfg.norm_eps, self._st()), "md_qkln_fwd"))
+
+    def _qkln_bwd(self, dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr):
+        self._prof("qk_layernorm", 6.0 * rows * width, lambda: hip.check(
+            self.L.md_qkln_bwd(dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr, self._st()), "md_qkln_bwd"))
+
+    def _attn_fwd(self, a):
+        nb = 2.0 * a.hd * (2 * a.Sq + 2 * a.Skv) * a.B * a.H
+        self._prof("attention", nb, lambda: hip.check(self.L.md_attn_fwd(byref(a), self._st()), "md_attn_fwd"))
+
     def _gemm(self, **kw):
         a = hip.GemmArgs()
         for k, v in kw.items():
@@ -128,17 +171,20 @@ class DiTEngine:
         if prof is not None:      # per-launch HIP events on the launch stream (bench.py roofline leg)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = -1
-        if self.gemm_prefer != hip.GEMM_AUTO:
-            a.variant = self.gemm_prefer
-            rc = self.L.md_gemm_bf16(byref(a), self._st())      # -1: the forced kernel refuses this problem (nothing was launched)
-            if rc == -1:
+        chosen = self._chosen
+        a.chosen_variant = ctypes.addressof(chosen)
+        rc = hip.NOT_ELIGIBLE
+        want = self.gemm_prefer if self.gemm_prefer != hip.GEMM_AUTO else a.variant
+        if want != hip.GEMM_AUTO:
+            a.variant = want
+            rc = self.L.md_gemm_bf16(byref(a), self._st())      # NOT_ELIGIBLE: the forced kernel refuses this problem (nothing was launched)
+            if rc == hip.NOT_ELIGIBLE:
                 a.variant = hip.GEMM_AUTO
-        if rc == -1:
+        if rc == hip.NOT_ELIGIBLE:
             rc = self.L.md_gemm_bf16(byref(a), self._st())
         hip.check(rc, "md_gemm_bf16")
-        if self.gemm_log is not None:
-            self.gemm_log.append((a.variant, a.M, a.N, a.K, a.batch))
+        if self.gemm_log is not None:      # the kernel the library actually launched (written back through chosen_variant)
+            self.gemm_log.append((chosen.value, a.M, a.N, a.K, a.batch))
         if prof is not None:
             e1.record()
             # algorithmic HBM bytes of the launch: both operands once, every output once (+ fused-epilogue operands)
@@ -189,8 +235,8 @@ class DiTEngine:
             out_us = out_rows * out_cols * batch * 4 / 4e6
             best, best_cost = None, None
             for ks in range(2, min(64, ws_cap, units) + 1):
-                if units % ks or t256 * ks < 128:
-                    continue
+                if units % ks or t256 * ks < getattr(self, "ksplit_min_items", 192):   # md_gemm_bf16's AUTO rule sends
+                    continue                                                           # < 192 tiles to the 2-stage kernels
                 per_wg = -(-t256 * ks // 256)
                 cost = per_wg * (contraction / ks / 64 * 1.9 + 5.0) + (ks + 2) * out_us
                 if best_cost is None or cost < best_cost:
@@ -210,6 +256,8 @@ class DiTEngine:
             self._gemm(C=out_ptr, M=M, N=N, K=K, ldc=ldo, sC=sOut, batch=batch, ksplit=1,
                        mode=hip.EPI_ACCUM_F32 if accumulate else hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
             return
+        if self.splitk_force_pp and self.gemm_prefer == hip.GEMM_AUTO:
+            operands = dict(operands, variant=hip.GEMM_PP256)
         self._gemm(C=self.ws.data_ptr(), M=M, N=N, K=K, ldc=N, sC=ks * M * N, sSplit=M * N, batch=batch, ksplit=ks,
                    mode=hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
         hip.check(self.L.md_splitk_reduce(self.ws.data_ptr(), out_ptr, M, N, ldo, sOut, ks, batch, 1 if accumulate else 0,
@@ -233,7 +281,7 @@ class DiTEngine:
                           _p(mean), _p(rstd), rows, C, C, C, ldmod, rps, pos_rows, self.cfg.norm_eps, act)
 
     def ln_fwd(self, a):
-        hip.check(self.L.md_ln_fwd(byref(a), self._st()), "md_ln_fwd")
+        self._prof("layernorm", 4.0 * a.rows * a.C, lambda: hip.check(self.L.md_ln_fwd(byref(a), self._st()), "md_ln_fwd"))
 
     @staticmethod
     def _rows_per_block(rows, rps):
@@ -256,7 +304,8 @@ class DiTEngine:
             dscale, ldg = scratch.data_ptr(), a.C
         b = hip.LnBwdArgs(dz.data_ptr(), _p(dx), dscale, dshift, _p(self.G[wname + ".weight"]) if wname else None,
                           a.C, a.C, ldg, rpb, 1 if accumulate else 0, is_out)
-        hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd")
+        self._prof("layernorm", (8.0 if accumulate else 6.0) * a.rows * a.C,
+                   lambda: hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd"))
 
     def attn_args(self, q, k, v, o, lse, B, H, Sq, Skv, ldq, ldk, ldv, hid, *, do=None, dq=None, dk=None, dv=None,
                   delta=None, lddq=0, lddk=0, lddv=0):
@@ -266,6 +315,9 @@ class DiTEngine:
                             Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd, 0)
 
     def _attn_bwd(self, a):
+        self._prof("attention", 2.0 * a.hd * (4 * a.Sq + 4 * a.Skv) * a.B * a.H, lambda: self._attn_bwd_launch(a))
+
+    def _attn_bwd_launch(self, a):
         rc = -1
         if self.attn_bwd_prefer != hip.ATTN_BWD_AUTO:
             a.bwd_split = self.attn_bwd_prefer
@@ -282,13 +334,13 @@ class DiTEngine:
         qkv = self.empty(M, 3 * hid)
         self.lin_fwd(xin, pre + ".qkv", qkv, M, 3 * hid, dim)
         rq = self.empty(2, M, dtype=F32)
-        hip.check(L.md_qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq[0].data_ptr(), self.cfg.norm_eps, st), "qkln")
-        hip.check(L.md_qkln_fwd(qkv.data_ptr(), M, 3 * hid, hid, hid, rq[1].data_ptr(), self.cfg.norm_eps, st), "qkln")
+        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq[0].data_ptr())
+        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, hid, hid, rq[1].data_ptr())
         o = self.empty(M, hid)
         lse = self.empty(B, heads, S, dtype=F32)
         a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
                            3 * hid, 3 * hid, 3 * hid, hid)
-        hip.check(L.md_attn_fwd(byref(a), st), "md_attn_fwd")
+        self._attn_fwd(a)
         t.qkv, t.rq, t.o, t.lse = qkv, rq, o, lse
         return o
 
@@ -302,8 +354,8 @@ class DiTEngine:
                            3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
                            dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
         self._attn_bwd(a)
-        hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq[0].data_ptr(), st), "qkln bwd")
-        hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * hid, hid, qkv.data_ptr(), 3 * hid, hid, M, hid, t.rq[1].data_ptr(), st), "qkln bwd")
+        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq[0].data_ptr())
+        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, hid, qkv.data_ptr(), 3 * hid, hid, M, hid, t.rq[1].data_ptr())
         self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim)
         dxin = self.empty(M, dim)
         self.lin_dgrad(dqkv, pre + ".qkv", dxin, M, 3 * hid, dim)
@@ -343,13 +395,13 @@ class DiTEngine:
         self.lin_fwd(ycond, n + ".cross_attn.kv_linear", t.kv, Mc, 2 * hx, d)
         t.rq2 = self.empty(M, dtype=F32)
         t.rk2 = self.empty(Mc, dtype=F32)
-        hip.check(L.md_qkln_fwd(t.q2.data_ptr(), M, hx, 0, hx, t.rq2.data_ptr(), cfg.norm_eps, st), "qkln")
-        hip.check(L.md_qkln_fwd(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.rk2.data_ptr(), cfg.norm_eps, st), "qkln")
+        self._qkln_fwd(t.q2.data_ptr(), M, hx, 0, hx, t.rq2.data_ptr())
+        self._qkln_fwd(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.rk2.data_ptr())
         t.o2 = self.empty(M, hx)
         t.lse2 = self.empty(B, bp.xheads, S, dtype=F32)
         ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc,
                             hx, 2 * hx, 2 * hx, hx)
-        hip.check(L.md_attn_fwd(byref(ax), st), "md_attn_fwd")
+        self._attn_fwd(ax)
         x2 = self.empty(M, d)
         self.lin_fwd(t.o2, n + ".cross_attn.proj", x2, M, d, hx, mode=hip.EPI_RESIDUAL, res=x1)
         t.x2 = x2
@@ -386,6 +438,8 @@ class DiTEngine:
             t.slot = self.empty(M, E, dtype=I32)
             hip.check(L.md_moe_route(logits.data_ptr(), t.probs.data_ptr(), ldl, B, S, E, k, t.rowidx.data_ptr(),
                                      t.gval.data_ptr(), t.slot.data_ptr(), st), "moe_route")
+            if self.route_override is not None and n in self.route_override:
+                self._override_routing(t, self.route_override[n], B, S, E, k)
             t.xin = self.empty(E, Bk, d)
             hip.check(L.md_gather_rows(t.xm3.data_ptr(), d, t.rowidx.data_ptr(), t.xin.data_ptr(), d, E * Bk, d, st), "gather")
             t.hpre = self.empty(E, Bk, f)
@@ -402,7 +456,21 @@ class DiTEngine:
                                        t.br3.data_ptr(), x3.data_ptr(), B, S, E, k, d, st), "moe_combine")
         return x3, t
 
-    def _block_bwd(self, bp: BlockPlan, t: Tape, dx, ycond, dycond_f32, B, S, Lc, gc, dgc_f32):
+    def _override_routing(self, t, m_idx, B, S, E, k):
+        """Parity-test hook (never on the product path): replace the expert-choice selection of one layer by given token
+        indices [B, E, k] (the fp32 oracle's top-k), keeping this run's own probabilities as gate values, so that what remains
+        of a difference to the oracle is arithmetic, not a slot ranked differently by bf16 gate logits."""
+        m_idx = m_idx.to(self.dev).long()
+        rows = (m_idx + (torch.arange(B, device=self.dev) * S).view(B, 1, 1)).permute(1, 0, 2).reshape(E, B * k)
+        t.rowidx.copy_(rows.to(I32))
+        ecol = torch.arange(E, device=self.dev).view(E, 1).expand(E, B * k)
+        t.gval.copy_(t.probs[rows, ecol])
+        slot = torch.full((B, S, E), -1, device=self.dev, dtype=I32)
+        for e in range(E):
+            slot[:, :, e].scatter_(1, m_idx[:, e, :], torch.arange(k, device=self.dev, dtype=I32).view(1, k).expand(B, k))
+        t.slot.copy_(slot.view(B * S, E))
+
+    def _block_bwd(self, bp: BlockPlan, t: Tape, dx, ycond, dycond_f32, B, S, Lc, gc, dgc_f32, group=None):
         """dx: grad w.r.t. the block output [M, d] (bf16), updated IN PLACE to the grad w.r.t. the block input."""
         L, st, cfg = self.L, self._st(), self.cfg
         d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
@@ -474,8 +542,8 @@ class DiTEngine:
                             2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
                             delta=delta, lddq=hx, lddk=2 * hx, lddv=2 * hx)
         self._attn_bwd(ax)
-        hip.check(L.md_qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr(), st), "qkln_bwd")
-        hip.check(L.md_qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr(), st), "qkln_bwd")
+        self._qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr())
+        self._qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr())
         self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)
         self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
         # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens
@@ -496,15 +564,67 @@ class DiTEngine:
         a1 = self.ln_args(t.x, n + ".norm1", None, M, d, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
         self.ln_bwd(a1, dxm1, dx, accumulate=True, wname=n + ".norm1", dscale=dmp + 4 * d, dshift=dmp, ldg=6 * d)
         # ---------------- adaLN linear: mod = W gelu(c) + b
-        self._adaln_bwd(n + ".adaLN_modulation.1", dmod, B, 6 * d, gc, dgc_f32)
+        self._adaln_bwd(n + ".adaLN_modulation.1", dmod, B, 6 * d, gc, dgc_f32, group)
 
-    def _adaln_bwd(self, wname, dmod_f32, B, N, gc, dgc_f32):
+    def _adaln_bwd(self, wname, dmod_f32, B, N, gc, dgc_f32, group=None):
+        """Backward of mod = W gelu(c) + b for one layer.  The weight / bias gradients are taken at once; the gradient w.r.t.
+        the condition vector, dgc += dmod @ W (a [B, N] x [N, D] product per layer, too small to fill the chip: 62 launches of
+        ~60 us per microbatch of 256 at ~50 TFLOP/s, profiles/r2_kernel_stats_bench_mb256.txt), is deferred when `group` is
+        given: the bf16 dmod goes to the group's slot and ALL layers of the group are contracted by one launch over operand
+        lists at the end of the backward (_adaln_dgrad_grouped)."""
         D = self.cfg.dim
-        dmod = self.empty(B, N)
+        if group is not None:
+            i = len(group["w"])
+            dmod = group["buf"][i]
+        else:
+            dmod = self.empty(B, N)
         hip.check(self.L.md_cast_f32_bf16(dmod_f32.data_ptr(), dmod.data_ptr(), B * N, None, self._st()), "cast")
         self.lin_wgrad(dmod, gc, wname, B, N, D, bias_from=dmod_f32)
+        if group is not None:
+            group["w"].append(self.S[wname + ".weight"].data_ptr())
+            return
         self.gemm_f32_acc(out_ptr=dgc_f32.data_ptr(), M=B, N=D, K=N, ldo=D, A=dmod.data_ptr(),
                           B=self.S[wname + ".weight"].data_ptr(), lda=N, ldb=D, a_kcontig=1, b_kcontig=0)
+
+    def _ptr_list(self, ptrs):
+        """Device array of device pointers (md_gemm_args.A_list / B_list); cached by value: with the fixed-address arenas the
+        same lists recur every microbatch, so the step path uploads nothing."""
+        key = tuple(ptrs)
+        t = self._ptr_cache.get(key)
+        if t is None:
+            if len(self._ptr_cache) > 256:
+                self._ptr_cache.clear()
+            t = torch.tensor(list(key), dtype=torch.int64).to(self.dev)
+            self._ptr_cache[key] = t
+        return t
+
+    def _adaln_dgrad_grouped(self, group, B, N, dgc_f32):
+        """dgc[B, D] += sum_l dmod_l[B, N] @ W_l[N, D] over the G layers of a group as ONE pp256 launch: every (layer, k-part)
+        is an item with its own operand pair (md_gemm_args.A_list / B_list) writing an fp32 slice, then one md_splitk_reduce."""
+        D, G = self.cfg.dim, len(group["w"])
+        if G == 0:
+            return
+        t256 = ((B + 255) // 256) * ((D + 255) // 256)
+        parts = 1
+        for c in (1, 2, 3, 4, 6, 8, 12):                      # k-parts per layer: enough items to fill the chip
+            if N % c == 0 and (N // c) % 128 == 0 and (N // c) >= 128:
+                parts = c
+                if t256 * G * c >= 192:
+                    break
+        kspan = N // parts
+        ks = G * parts
+        if ks * B * D > self.ws.numel() or (N // parts) % 128:
+            for i in range(G):                                 # does not fit the workspace / the kernel: layer by layer
+                self.gemm_f32_acc(out_ptr=dgc_f32.data_ptr(), M=B, N=D, K=N, ldo=D, A=group["buf"][i].data_ptr(), B=group["w"][i],
+                                  lda=N, ldb=D, a_kcontig=1, b_kcontig=0)
+            return
+        base = group["buf"].data_ptr()
+        al = self._ptr_list([base + 2 * (i * B * N + c * kspan) for i in range(G) for c in range(parts)])
+        bl = self._ptr_list([w + 2 * (c * kspan * D) for w in group["w"] for c in range(parts)])
+        self._gemm(A=base, B=group["w"][0], A_list=al.data_ptr(), B_list=bl.data_ptr(), C=self.ws.data_ptr(), M=B, N=D, K=kspan * ks,
+                   lda=N, ldb=D, ldc=D, sC=ks * B * D, sSplit=B * D, batch=1, ksplit=ks, a_kcontig=1, b_kcontig=0,
+                   mode=hip.EPI_STORE_F32, act=0, alpha=1.0)
+        hip.check(self.L.md_splitk_reduce(self.ws.data_ptr(), dgc_f32.data_ptr(), B, D, D, 0, ks, 1, 1, self._st()), "md_splitk_reduce")
 
     # ------------------------------------------------------------------------------------------ small MLPs (Mlp with norm)
     def _mlp_norm_fwd(self, pre, xin, rows, cin, rps, res=None):
@@ -542,10 +662,14 @@ class DiTEngine:
     # ------------------------------------------------------------------------------------------ whole model
     def forward(self, x_img: torch.Tensor, t_in: torch.Tensor, y: torch.Tensor, *, mask_ratio: float = 0.0,
                 mask_noise: Optional[torch.Tensor] = None, in_scale: Optional[torch.Tensor] = None,
-                y_rowscale: Optional[torch.Tensor] = None) -> Tape:
+                y_rowscale: Optional[torch.Tensor] = None, record_tape: bool = False, arena: bool = False) -> Tape:
         """x_img f32 [B,C,H,W] (multiplied by in_scale[b] if given), t_in f32 [B], y f16|f32 [B,(1,)L,Dc]
-        (rows multiplied by y_rowscale[b] if given).  Returns the tape; tape.tok is the network output for the
-        kept tokens, bf16 [B*Tk, p*p*C]."""
+        (rows multiplied by y_rowscale[b] if given).  Returns the tape; tape.out_tok is the network output for the
+        kept tokens, bf16 [B*Tk, p*p*C].
+        record_tape: a backward() will follow — keep every block's activations (inference passes drop them as they go).
+        arena: additionally place the tape in the fixed-address arena (needs `use_arena`; the caller promises forward ->
+        backward strictly in turn).  Both are explicit arguments: torch disables grad mode inside autograd.Function.forward,
+        so probing torch.is_grad_enabled() here would never see a training pass."""
         cfg, L, st = self.cfg, self.L, self._st()
         B = x_img.shape[0]
         C, H, W, p = cfg.in_channels, x_img.shape[-2], x_img.shape[-1], cfg.patch_size
@@ -553,15 +677,19 @@ class DiTEngine:
         assert T == cfg.tokens, "input resolution does not match the model's position table"
         Lc, Dc = y.shape[-2], y.shape[-1]
         assert x_img.dtype == F32 and x_img.is_contiguous() and y.is_contiguous() and y.dtype in (torch.float16, F32)
-        grad_pass = self.use_arena and torch.is_grad_enabled()
+        grad_pass = self.use_arena and arena and record_tape
+        self._record = record_tape or self.keep_last_tape
         if grad_pass:
             self._tape_arena.begin((B, H, W, Lc, Dc, float(mask_ratio), str(y.dtype)))
             self._arena = self._tape_arena
+        ok = False
         try:
-            return self._forward(x_img, t_in, y, mask_ratio, mask_noise, in_scale, y_rowscale)
+            tp = self._forward(x_img, t_in, y, mask_ratio, mask_noise, in_scale, y_rowscale)
+            ok = True
+            return tp
         finally:
             if grad_pass:
-                self._tape_arena.end()
+                self._tape_arena.end(ok)
             self._arena = None
 
     def _forward(self, x_img, t_in, y, mask_ratio, mask_noise, in_scale, y_rowscale) -> Tape:
@@ -656,7 +784,8 @@ class DiTEngine:
         tp.mixer = []
         for bp in self.mixer:
             x, bt = self._block_fwd(bp, x, ym, B, T, Lc, gc)
-            tp.mixer.append(bt)
+            if self._record:
+                tp.mixer.append(bt)
         # ---- masking, dit.py:495-504
         Wd = x.shape[1]
         if mask_ratio > 0:
@@ -687,7 +816,8 @@ class DiTEngine:
         tp.blocks = []
         for bp in self.backbone:
             x, bt = self._block_fwd(bp, x, y2, B, Tk, Lc, gc)
-            tp.blocks.append(bt)
+            if self._record:
+                tp.blocks.append(bt)
         # ---- final layer, dit.py:513
         tp.xlast = x
         tp.fmod = self.empty(B, 2 * D)
@@ -700,6 +830,8 @@ class DiTEngine:
         pv = cfg.patch_vec
         tp.out_tok = self.empty(B * Tk, pv)
         self.lin_fwd(tp.xf, "final_layer.linear", tp.out_tok, B * Tk, pv, D)
+        if self.keep_last_tape:
+            self.last_tape = tp
         return tp
 
     def sample_image(self, tp: Tape) -> torch.Tensor:
@@ -719,11 +851,13 @@ class DiTEngine:
         if use:
             self._scratch_arena.begin((tp.B, tp.T, tp.Tk, tp.Lc, tp.H, tp.W))
             self._arena = self._scratch_arena
+        ok = False
         try:
             self._backward(tp, dtok, on_segment)
+            ok = True
         finally:
             if use:
-                self._scratch_arena.end()
+                self._scratch_arena.end(ok)
             self._arena = None
 
     def _block_bwd_scoped(self, *a):
@@ -743,6 +877,12 @@ class DiTEngine:
         gc = tp.gc
         dgc = self.zeros(B, D)                      # fp32: sums the adaLN dgrads of all 6+28+1 layers
         dy2_f32 = self.zeros(Mc, D)                 # fp32: caption-token grads from the 28 backbone kv_linears + pooling
+        grp_b = grp_m = None
+        if self.group_adaln:                        # bf16 dmod of every layer, kept until the grouped contraction below
+            if self.backbone:
+                grp_b = {"buf": self.empty(len(self.backbone), B, 6 * self.backbone[0].dim), "w": []}
+            if self.mixer:
+                grp_m = {"buf": self.empty(len(self.mixer), B, 6 * self.mixer[0].dim), "w": []}
         # ---- final layer
         self.lin_wgrad(dtok, tp.xf, "final_layer.linear", B * Tk, pv, D)
         dxf = self.empty(B * Tk, D)
@@ -758,7 +898,7 @@ class DiTEngine:
         seg("final_layer")
         # ---- backbone
         for bp, bt in zip(reversed(self.backbone), reversed(tp.blocks)):
-            self._block_bwd_scoped(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc)
+            self._block_bwd_scoped(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc, grp_b)
             seg(bp.name)
         # ---- mixer -> backbone projection
         if cfg.use_patch_mixer and cfg.has_maps:
@@ -779,7 +919,7 @@ class DiTEngine:
         has_maps = cfg.use_patch_mixer and cfg.has_maps
         dym_f32 = self.zeros(Mc, Dm) if has_maps else dy2_f32
         for bp, bt in zip(reversed(self.mixer), reversed(tp.mixer)):
-            self._block_bwd_scoped(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc)
+            self._block_bwd_scoped(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc, grp_m)
             seg(bp.name)
         # ---- map_xin / patch embedding
         if has_maps:
@@ -796,6 +936,10 @@ class DiTEngine:
                           A=dtok_e.data_ptr(), B=tp.patches.data_ptr(), lda=D, ldb=pv, a_kcontig=0, b_kcontig=0)
         hip.check(L.md_colsum(dtok_e.data_ptr(), 0, D, self.G["x_embedder.proj.bias"].data_ptr(), B * T, D, st), "colsum")
         # ---- condition vector: c = temb + pooled ; gc = gelu(c)
+        if grp_b is not None:
+            self._adaln_dgrad_grouped(grp_b, B, 6 * self.backbone[0].dim, dgc)
+        if grp_m is not None:
+            self._adaln_dgrad_grouped(grp_m, B, 6 * self.mixer[0].dim, dgc)
         dc = self.empty(B, D)
         hip.check(L.md_act_bwd(dgc.data_ptr(), tp.c.data_ptr(), dc.data_ptr(), B * D, hip.ACT_GELU_TANH, st), "act_bwd")
         # timestep embedder

@@ -106,7 +106,7 @@ class GemmArgs(Structure):
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
-        ("timeline", c_void_p),
+        ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p),
     ]
 
 
@@ -139,10 +139,13 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+NOT_ELIGIBLE = -2      # MD_NOT_ELIGIBLE: the forced kernel variant does not cover the problem (nothing was launched)
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
-        raise RuntimeError(f"{what} failed with code {code} "
-                           f"({'bad argument' if code == -1 else 'hipError_t'})")
+        why = {-1: "bad argument", NOT_ELIGIBLE: "forced kernel variant not eligible for this problem"}.get(code, "hipError_t")
+        raise RuntimeError(f"{what} failed with code {code} ({why})")
 
 
 # name -> argtypes; every function returns int and takes the stream last.
@@ -218,10 +221,12 @@ _sig("md_moe_combine", P, P, P, P, P, I64, P, P, I64, I64, I32, I32, I64, P)
 _sig("md_moe_combine_bwd", P, P, P, P, P, P, I64, I64, P)
 _sig("md_moe_dispatch_bwd", P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I64, P)
 _sig("md_edm_prepare", P, P, P, P, P, P, P, I64, I64, F32, F32, F32, P)
+_sig("md_edm_prepare_f16", P, P, P, P, P, P, P, P, I64, I64, F32, F32, F32, P)
 _sig("md_patchify", P, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_timestep_embed", P, P, I64, I32, P)
 _sig("md_unpatchify", P, P, I64, P, P, I64, I32, I32, I32, I32, P)
 _sig("md_edm_loss", P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I32, F32, P)
+_sig("md_edm_loss_train", P, P, P, P, P, P, P, P, F32, P, F32, I64, I64, I32, I32, I32, I32, F32, P)
 _sig("md_edm_sampler_input", P, P, I64, F32, F32, I32, P)
 _sig("md_edm_heun_update", P, P, P, P, P, I64, F32, I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, F32, I32, P)
 _sig("md_sumsq", P, I32, I64, P, P)
@@ -254,7 +259,7 @@ def stream_ptr():
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
-         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0):
+         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, chosen=None):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
     def ptr(x):
         if x is None:
@@ -263,8 +268,12 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
-                 ptr(timeline))
+                 ptr(timeline), None, ptr(A_list), ptr(B_list))
+    ch = ctypes.c_int32(-1)
+    a.chosen_variant = ctypes.addressof(ch)
     rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())
+    if chosen is not None:
+        chosen.append(ch.value)
     if expect is None:
         return rc
     check(rc, "md_gemm_bf16")

@@ -78,7 +78,8 @@ class LatentDiffusion(nn.Module):
                 frozen.requires_grad_(False)
 
     # ---------------------------------------------------------------------------------------- training step
-    def forward(self, batch: dict):
+    def _inputs(self, batch: dict):
+        """(latents, conditioning, per-sample caption scale or None) of a batch (model.py:105-135)."""
         if self.precomputed_latents and self.image_latents_key in batch:
             latents = batch[self.image_latents_key]        # already multiplied by the VAE scaling factor
         else:
@@ -95,42 +96,90 @@ class LatentDiffusion(nn.Module):
                 conditioning = self.text_encoder.encode(captions, attention_mask=batch["attention_mask"].view(-1, captions.shape[-1]))[0]
             else:
                 conditioning = self.text_encoder.encode(captions)[0]
-        if "drop_caption_mask" in batch.keys():            # in place on the batch tensor, like model.py:132-135
-            conditioning *= batch["drop_caption_mask"].view([-1] + [1] * (len(conditioning.shape) - 1)).to(conditioning.dtype)
-        loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio)
+        # Dropped captions (model.py:131-135 multiplies the batch tensor by the 0/1 mask in place): here the mask rides along
+        # as a per-sample row scale of the first kernel that touches the captions (md_cast_rows_bf16), so no torch op runs and
+        # the batch tensor is left as the loader produced it.
+        drop = batch.get("drop_caption_mask") if hasattr(batch, "get") else None
+        if drop is not None:
+            drop = drop.reshape(-1)
+            if drop.dtype != torch.float32 or not drop.is_contiguous():
+                drop = drop.float().contiguous()
+        return latents, conditioning, drop
+
+    def forward(self, batch: dict):
+        latents, conditioning, drop = self._inputs(batch)
+        loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio,
+                             _y_rowscale=drop)
         return (loss, latents, conditioning)
 
-    def edm_loss(self, x: torch.Tensor, y: torch.Tensor, mask_ratio: float = 0, _noise=None, **kwargs) -> torch.Tensor:
-        """model.py:181-210 on the HIP engine.  `_noise=(rnd_normal, eps, mask_noise)` injects the three random
-        draws (parity tests); otherwise they are drawn here in the reference's order."""
+    def _draws(self, x: torch.Tensor, T: int, mask_ratio: float):
+        """The three random draws in the reference's order (model.py:182,188, utils.py:390): randn[B,1,1,1], randn_like(x.float()),
+        rand[B,T]."""
+        B = x.shape[0]
+        rnd = torch.randn([B, 1, 1, 1], device=x.device)
+        if x.dtype == torch.float32:
+            eps = self.randn_like(x)
+        elif self.randn_like is torch.randn_like:
+            eps = torch.randn_like(x, dtype=torch.float32)
+        else:
+            eps = self.randn_like(x.float())
+        mnoise = torch.rand(B, T, device=x.device) if mask_ratio > 0 else None
+        return rnd, eps, mnoise
+
+    def _prep(self, x, y, mask_ratio, _noise):
         dit = self.dit
         dit._ensure_flat()
         dit.refresh_shadow()
-        eng = dit._engine
-        cfg = self.edm_config
-        x = x.detach().float().contiguous()
+        x = x.detach()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        x = x.contiguous()
         B = x.shape[0]
         T = (x.shape[-2] // dit.patch_size) * (x.shape[-1] // dit.patch_size)
         if _noise is None and getattr(self, "_noise_fn", None) is not None:
             _noise = self._noise_fn(B)            # test hook: recorded (rnd_normal, eps, mask_noise) per call
-        if _noise is None:
-            rnd = torch.randn([B, 1, 1, 1], device=x.device)
-            eps = self.randn_like(x)
-            mnoise = torch.rand(B, T, device=x.device) if mask_ratio > 0 else None
-        else:
-            rnd, eps, mnoise = _noise
+        rnd, eps, mnoise = self._draws(x, T, mask_ratio) if _noise is None else _noise
         if mask_ratio > 0:
             assert dit.training, "Masking is only recommended during training"
         y = y.detach()
         if y.dtype not in (torch.float16, torch.float32):
             y = y.float()
         y = y.contiguous()
+        rnd = rnd.reshape(B)
+        if rnd.dtype != torch.float32 or not rnd.is_contiguous():
+            rnd = rnd.float().contiguous()
+        if eps.dtype != torch.float32 or not eps.is_contiguous():
+            eps = eps.float().contiguous()
+        return x, y, rnd, eps, mnoise
+
+    def edm_loss(self, x: torch.Tensor, y: torch.Tensor, mask_ratio: float = 0, _noise=None, _y_rowscale=None, **kwargs) -> torch.Tensor:
+        """model.py:181-210 on the HIP engine.  `_noise=(rnd_normal, eps, mask_noise)` injects the three random
+        draws (parity tests); otherwise they are drawn here in the reference's order.  `_y_rowscale` [B] f32: per-sample
+        factor on the caption rows (the caption-drop mask)."""
+        x, y, rnd, eps, mnoise = self._prep(x, y, mask_ratio, _noise)
+        dit = self.dit
         need_grad = torch.is_grad_enabled() and dit._plist[0].requires_grad
-        args = (self, dit._grad_anchor, x, y, rnd.reshape(B).float().contiguous(), eps.float().contiguous(), mnoise,
-                float(mask_ratio))
+        args = (self, dit._grad_anchor, x, y, rnd, eps, mnoise, float(mask_ratio), _y_rowscale)
         if need_grad:
             return _EDMLossFunction.apply(*args)
         return _edm_forward(*args)[0]
+
+    def train_microbatch(self, batch: dict, grad_scale: float = 1.0, loss_accum: Optional[torch.Tensor] = None,
+                         accum_weight: float = 0.0, _noise=None) -> torch.Tensor:
+        """forward + backward of one microbatch WITHOUT autograd: what `(model(batch)[0] * grad_scale).backward()` does
+        (Composer's microbatch loop around model.py:104-142), as one explicit launch sequence — every operation on device
+        data is a HIP kernel of libmicrodit_hip (the three random draws are torch's).  Parameter gradients accumulate in the
+        flat fp32 buffer (the .grad views); `loss_accum` (1-element f32 tensor) += accum_weight * loss on the device.
+        Returns the microbatch loss (device scalar)."""
+        latents, conditioning, drop = self._inputs(batch)
+        mask_ratio = self.train_mask_ratio if self.training else self.eval_mask_ratio
+        x, y, rnd, eps, mnoise = self._prep(latents, conditioning, mask_ratio, _noise)
+        dit = self.dit
+        loss, tape, dtb = _edm_forward(self, None, x, y, rnd, eps, mnoise, float(mask_ratio), drop,
+                                       train=(float(grad_scale), loss_accum, float(accum_weight)))
+        dit.attach_grads()
+        dit._engine.backward(tape, dtb, on_segment=getattr(dit, "_on_segment", None))
+        return loss
 
     def model_forward_wrapper(self, x, sigma, y, model_forward_fxn, mask_ratio: float, **kwargs) -> dict:
         """EDM preconditioning around an arbitrary forward fn (model.py:144-179); used by the sampler."""
@@ -251,8 +300,12 @@ class LatentDiffusion(nn.Module):
         return (image / 2 + 0.5).clamp(0, 1).float().detach()
 
 
-def _edm_forward(model: LatentDiffusion, anchor, x, y, rnd, eps, mnoise, mask_ratio):
-    """Forward half of the fused training step.  Returns (loss scalar tensor, tape, dtok_f32)."""
+def _edm_forward(model: LatentDiffusion, anchor, x, y, rnd, eps, mnoise, mask_ratio, y_rowscale=None, train=None,
+                 record_tape: bool = False):
+    """Forward half of the fused training step.  Returns (loss scalar tensor, tape, dtok).
+    train = (grad_scale, loss_accum, accum_weight): the Trainer's autograd-free form — the tape goes to the engine's
+    fixed-address arena and dtok comes back as bf16, already multiplied by grad_scale (md_edm_loss_train).  Otherwise dtok is
+    fp32 and unscaled (the autograd node scales it by the upstream gradient)."""
     dit = model.dit
     eng = dit._engine
     L = hip.lib()
@@ -260,28 +313,44 @@ def _edm_forward(model: LatentDiffusion, anchor, x, y, rnd, eps, mnoise, mask_ra
     ec = model.edm_config
     B, C, H, W = x.shape
     dev = x.device
-    xn = torch.empty_like(x)
+    xn = torch.empty(x.shape, device=dev, dtype=torch.float32)
     sigma, cin, cnoise = (torch.empty(B, device=dev) for _ in range(3))
-    hip.check(L.md_edm_prepare(x.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn.data_ptr(), sigma.data_ptr(), cin.data_ptr(),
-                               cnoise.data_ptr(), B, C * H * W, ec.P_mean, ec.P_std, ec.sigma_data, st), "md_edm_prepare")
-    tape = eng.forward(xn, cnoise, y, mask_ratio=mask_ratio, mask_noise=mnoise, in_scale=cin)
+    if x.dtype == torch.float16:
+        x0 = torch.empty(x.shape, device=dev, dtype=torch.float32)
+        hip.check(L.md_edm_prepare_f16(x.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(),
+                                       cin.data_ptr(), cnoise.data_ptr(), B, C * H * W, ec.P_mean, ec.P_std, ec.sigma_data, st),
+                  "md_edm_prepare_f16")
+    else:
+        x0 = x
+        hip.check(L.md_edm_prepare(x.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn.data_ptr(), sigma.data_ptr(), cin.data_ptr(),
+                                   cnoise.data_ptr(), B, C * H * W, ec.P_mean, ec.P_std, ec.sigma_data, st), "md_edm_prepare")
+    tape = eng.forward(xn, cnoise, y, mask_ratio=mask_ratio, mask_noise=mnoise, in_scale=cin, y_rowscale=y_rowscale,
+                       record_tape=record_tape or train is not None, arena=train is not None)
     lps = torch.empty(B, device=dev)
     loss = torch.empty(1, device=dev)
-    dtok = torch.empty(B * tape.Tk, dit.config.patch_vec, device=dev)
-    hip.check(L.md_edm_loss(tape.out_tok.data_ptr(), None if tape.keep_rows is None else tape.keep_rows.data_ptr(),
-                            xn.data_ptr(), x.data_ptr(), sigma.data_ptr(), lps.data_ptr(), loss.data_ptr(), dtok.data_ptr(), B,
-                            tape.Tk, C, H, W, dit.patch_size, ec.sigma_data, st), "md_edm_loss")
+    keep = None if tape.keep_rows is None else tape.keep_rows.data_ptr()
+    if train is not None:
+        gscale, accum, aw = train
+        dtok = torch.empty(B * tape.Tk, dit.config.patch_vec, device=dev, dtype=torch.bfloat16)
+        hip.check(L.md_edm_loss_train(tape.out_tok.data_ptr(), keep, xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(), lps.data_ptr(),
+                                      loss.data_ptr(), dtok.data_ptr(), gscale, None if accum is None else accum.data_ptr(), aw, B,
+                                      tape.Tk, C, H, W, dit.patch_size, ec.sigma_data, st), "md_edm_loss_train")
+    else:
+        dtok = torch.empty(B * tape.Tk, dit.config.patch_vec, device=dev) if record_tape else None
+        hip.check(L.md_edm_loss(tape.out_tok.data_ptr(), keep, xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(), lps.data_ptr(),
+                                loss.data_ptr(), None if dtok is None else dtok.data_ptr(), B, tape.Tk, C, H, W, dit.patch_size,
+                                ec.sigma_data, st), "md_edm_loss")
     tape.loss_per_sample = lps
     return loss.reshape(()), tape, dtok
 
 
 class _EDMLossFunction(torch.autograd.Function):
-    """loss = EDM(x, y) as one autograd node; backward runs the engine's hand-written backward and accumulates the
-    parameter gradients straight into the flat fp32 grad buffer (the .grad views)."""
+    """loss = EDM(x, y) as one autograd node (the drop-in `loss.backward()` surface); backward runs the engine's hand-written
+    backward and accumulates the parameter gradients straight into the flat fp32 grad buffer (the .grad views)."""
 
     @staticmethod
-    def forward(ctx, model, anchor, x, y, rnd, eps, mnoise, mask_ratio):
-        loss, tape, dtok = _edm_forward(model, anchor, x, y, rnd, eps, mnoise, mask_ratio)
+    def forward(ctx, model, anchor, x, y, rnd, eps, mnoise, mask_ratio, y_rowscale):
+        loss, tape, dtok = _edm_forward(model, anchor, x, y, rnd, eps, mnoise, mask_ratio, y_rowscale, record_tape=True)
         ctx.model, ctx.tape, ctx.dtok = model, tape, dtok
         return loss
 
@@ -296,7 +365,7 @@ class _EDMLossFunction(torch.autograd.Function):
                                              torch.cuda.current_stream().cuda_stream), "md_cast_f32_bf16")
         dit._engine.backward(tape, dtb, on_segment=getattr(dit, "_on_segment", None))
         ctx.tape = ctx.dtok = None
-        return None, torch.zeros_like(dit._grad_anchor), None, None, None, None, None, None
+        return None, torch.zeros_like(dit._grad_anchor), None, None, None, None, None, None, None
 
 
 class _FrozenStub(nn.Module):

@@ -139,6 +139,58 @@ class FusedAdamW:
         if self.ema is not None and "ema" in sd:
             self.ema.copy_(sd["ema"])
             self.ema_live = bool(sd.get("ema_live", True))
+        elif self.ema is not None and self.step_count > self.ema_start:
+            # resuming past ema_start from a checkpoint that holds no EMA: the average would silently restart from the
+            # current weights.  That is what Composer's EMA does when it is first enabled, but it must not go unnoticed.
+            import warnings
+            warnings.warn(f"optimizer state at step {self.step_count} (> ema_start {self.ema_start}) carries no EMA weights: "
+                          "the EMA restarts from the current weights")
+        elif self.ema is None and "ema" in sd:
+            import warnings
+            warnings.warn("the checkpoint carries EMA weights but this run configures no EMA: they are dropped")
+
+    # ------------------------------------------------------------------ EMA weights for evaluation / export
+    def ema_state_dict(self):
+        """The EMA weights as a model state_dict (same keys / shapes as dit.state_dict() for parameters), or None before the
+        first EMA batch.  Saved by train.py next to the raw weights (Composer's EMA algorithm keeps them in its own state)."""
+        if self.ema is None or not self.ema_live:
+            return None
+        f = self.dit.flat_buffers()
+        out = {}
+        for name, view in f["P"].items():
+            o = f["offs"][name]
+            out[name] = self.ema[o:o + view.numel()].view(view.shape)
+        return out
+
+    class _EmaSwap:
+        def __init__(self, opt):
+            self.opt = opt
+
+        def __enter__(self):
+            o = self.opt
+            self.active = o.ema is not None and o.ema_live
+            if self.active:                       # off the step path: plain tensor swaps, then re-derive the bf16 shadow
+                f = o.dit.flat_buffers()
+                tmp = f["p"].clone()
+                f["p"].copy_(o.ema)
+                o.ema.copy_(tmp)
+                o.dit.refresh_shadow(force=True)
+            return self.active
+
+        def __exit__(self, *exc):
+            if self.active:
+                o = self.opt
+                f = o.dit.flat_buffers()
+                tmp = f["p"].clone()
+                f["p"].copy_(o.ema)
+                o.ema.copy_(tmp)
+                o.dit.refresh_shadow(force=True)
+            return False
+
+    def swap_ema(self):
+        """Context manager: the model computes with the EMA weights inside (Composer's EMA swaps them in for evaluation);
+        a no-op before the first EMA batch."""
+        return FusedAdamW._EmaSwap(self)
 
 
 class GradSync:
@@ -183,6 +235,8 @@ class GradSync:
         self.pending = []
         self.active = False
         self.buckets = 0                 # buckets handed over in the current step (= partial-sum slots in use)
+        self.last_buckets = 0            # ... in the last finished step (bench.py dp block)
+        self.step_bytes = self.last_bytes = 0   # bytes handed to the collective in the current / last step
         self.norm_partials: Optional[torch.Tensor] = None     # set by the Trainer: FusedAdamW.partials
         self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.enabled) else None
         self.side = torch.cuda.Stream(device=f["g"].device) if (self.enabled and f["g"].is_cuda) else None
@@ -211,6 +265,7 @@ class GradSync:
             work = dist.all_reduce(buf, group=self.pg, async_op=True)
         slot = self.buckets
         self.buckets += 1
+        self.step_bytes += buf.numel() * buf.element_size()
         if self.norm_partials is not None and self.side is not None and slot < FusedAdamW.MAX_BUCKETS:
             if work is None:
                 self.side.wait_stream(torch.cuda.current_stream())
@@ -250,7 +305,8 @@ class GradSync:
         n = self.buckets if (self.norm_partials is not None and self.side is not None and 0 < self.buckets <= FusedAdamW.MAX_BUCKETS) else 0
         if self.side is not None and self.buckets:
             torch.cuda.current_stream().wait_stream(self.side)
-        self.buckets = 0
+        self.last_buckets, self.last_bytes = self.buckets, self.step_bytes
+        self.buckets = self.step_bytes = 0
         return n
 
 
@@ -270,28 +326,78 @@ class Trainer:
         self.batches_seen = 0
         self.log = log
         self._win: List[tuple] = []
+        self.measure_comm = False          # bench.py: event pairs around GradSync.finish() (exposed exchange time)
+        self._comm_events: List[tuple] = []
 
     def train_step(self, batch: dict) -> torch.Tensor:
-        """One optimisation step on this rank's share of the global batch.  Returns the (detached) rank-mean loss."""
+        """One optimisation step on this rank's share of the global batch.  Returns the rank-mean loss (device scalar).
+        Microbatch i contributes with weight n_i / n (Composer scales each microbatch loss by its share of the rank batch before
+        backward): the weight goes into md_edm_loss_train, which pre-multiplies dL/dF and accumulates the
+        weighted loss on the device — no autograd graph and no torch arithmetic on the step path."""
         model = self.model
-        n = batch["image_latents"].shape[0]
+        n = batch[model.image_latents_key if model.image_latents_key in batch else model.image_key].shape[0]
         mb = min(self.microbatch_size, n)
         starts = list(range(0, n, mb))
-        total = None
+        total = torch.empty(1, device=model.dit.flat_buffers()["p"].device)       # a fresh scalar per step: callers keep them
+        hip.check(hip.lib().md_fill_zero(total.data_ptr(), 4, torch.cuda.current_stream().cuda_stream), "md_fill_zero")
         for i, s in enumerate(starts):
             part = {k: (v[s:s + mb] if torch.is_tensor(v) and v.shape[0] == n else v) for k, v in batch.items()}
             self.sync.active = (i == len(starts) - 1)
-            loss = model(part)[0]
-            w = part["image_latents"].shape[0] / n
-            (loss * w).backward()
-            total = loss.detach() * w if total is None else total + loss.detach() * w
+            w = min(mb, n - s) / n
+            model.train_microbatch(part, grad_scale=w, loss_accum=total, accum_weight=w)
         self.sync.active = False
+        if self.measure_comm:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                  # behind the last backward kernel on the compute stream
         slots = self.sync.finish()
+        if self.measure_comm:
+            e1.record()                                  # behind the waits on the collectives / side-stream norms
+            self._comm_events.append((e0, e1))
         fac = self.schedule.factor(self.batches_seen) if self.schedule is not None else 1.0
         self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
                       g_bf16=self.sync.gbf, norm_partials=slots * hip.SUMSQ_PARTIALS)
         self.batches_seen += 1
-        return total
+        return total.reshape(())
+
+    def exposed_comm_ms(self, last: int = 0) -> Optional[float]:
+        """Mean time per step the compute stream spent waiting for the gradient exchange after the last backward kernel was
+        enqueued (needs measure_comm; synchronises).  `last` > 0: only the most recent steps (skip warm-up)."""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize()
+        ev = self._comm_events[-last:] if last > 0 else self._comm_events
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def sync_replicas(self) -> None:
+        """Make every rank's weights and optimiser state bit-identical to rank 0's (call once after initialisation / resume).
+        Data parallelism here replicates the weights and relies on identical updates from then on; nothing else would catch a
+        replica that started from a different state."""
+        if self.world <= 1:
+            return
+        f = self.model.dit.flat_buffers()
+        bufs = [f["p"], self.opt.m, self.opt.v] + ([self.opt.ema] if self.opt.ema is not None else [])
+        for t in bufs:
+            if self.sync.host_bounce:
+                h = t.cpu()
+                dist.broadcast(h, src=0, group=self.sync.pg)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=0, group=self.sync.pg)
+        self.model.dit.refresh_shadow(force=True)
+
+    def replicas_in_sync(self) -> bool:
+        """True when the fp32 master weights of all ranks have the same checksum (sum and sum of squares in fp64); cheap enough
+        to run every few hundred batches."""
+        if self.world <= 1:
+            return True
+        p = self.model.dit.flat_buffers()["p"].double()
+        mine = torch.stack([p.sum(), (p * p).sum()])
+        lo, hi = mine.clone(), mine.clone()
+        if self.sync.host_bounce:
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.sync.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.sync.pg)
+        return bool(torch.equal(lo, hi))
 
     def throughput(self, global_batch: int, window: int = 3) -> Optional[float]:
         """Composer SpeedMonitor(window_size=3) definition: samples over the last `window` batches / wall time."""

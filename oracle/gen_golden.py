@@ -191,10 +191,10 @@ def gen_curve(steps=1000):
     print("tiny_curve_1k.npz")
 
 
-def gen_curve_hot(steps=300):
+def gen_curve_hot(steps=1000):
     """The same run where the network matters from step 0: zero-initialised tensors de-zeroed
     (oracle.dezero_state_dict), constant learning rate 2.4e-4 (no warm-up), clip 0.25: the loss falls from ~1.3 to ~0.75
-    within 300 steps and the clip is active throughout."""
+    within 300 steps (to ~0.6 by step 1000) and the clip is active throughout."""
     cfg = orc.tiny_config()
     torch.manual_seed(18)
     dit = ref_dit_from_cfg(cfg)
@@ -251,6 +251,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "xl2":
         # BASELINE.json configs[1] geometry (MicroDiT_XL_2, dit.py:671-709), batch 2: ~25 GB of host memory, ~1 min
         gen_model("xl2_mask75", orc.xl2_config(), 2, 41, 0.75, -0.6, 1.2, 77)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2_mask0":
+        # BASELINE.json configs[3] geometry (configs/res_256_finetune.yaml: mask 0 -> all 256 tokens reach the backbone), batch 2
+        gen_model("xl2_mask0", orc.xl2_config(), 2, 43, 0.0, -0.6, 1.2, 77)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2_res512":
+        # BASELINE.json configs[4] geometry (configs/res_512_pretrain.yaml: 64 x 64 latents -> 1024 mixer tokens,
+        # pos_interp_scale 2.0, mask 0.75 -> 256 backbone tokens, P_mean 0 / P_std 0.6), batch 1
+        gen_model("xl2_res512_mask75", orc.xl2_config(input_size=64, pos_interp_scale=2.0), 1, 45, 0.75, 0.0, 0.6, 77)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sampler":
         gen_sampler()

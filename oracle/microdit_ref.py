@@ -236,8 +236,9 @@ def modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
     return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
 
 
-def dit_block(sd: SD, spec: BlockSpec, cfg: RefConfig, x: Tensor, y: Tensor, c: Tensor) -> Tensor:
-    """dit.py:232-239."""
+def dit_block(sd: SD, spec: BlockSpec, cfg: RefConfig, x: Tensor, y: Tensor, c: Tensor, taps: Optional[dict] = None) -> Tensor:
+    """dit.py:232-239.  `taps` (tests): receives the block output and, for expert-choice blocks, the top-k token indices
+    [n, e, k] (so a product run can be fed the oracle's routing and routing flips separated from arithmetic error)."""
     p, eps = spec.prefix, cfg.norm_eps
     mod = _lin(sd, p + ".adaLN_modulation.1", _gelu_tanh(c))
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
@@ -245,8 +246,15 @@ def dit_block(sd: SD, spec: BlockSpec, cfg: RefConfig, x: Tensor, y: Tensor, c: 
                                               spec.heads, eps)
     x = x + cross_attention(sd, p + ".cross_attn", _ln_w(sd, p + ".norm2", x, eps), y, spec.xheads, eps)
     hin = modulate(_ln_w(sd, p + ".norm3", x, eps), sh_m, sc_m)
-    ff = ec_moe(sd, p + ".mlp", hin, cfg.num_experts, cfg.expert_capacity) if spec.moe else swiglu(sd, p + ".mlp", hin)
-    return x + g_m.unsqueeze(1) * ff
+    if spec.moe and taps is not None:
+        ff, m, _ = ec_moe(sd, p + ".mlp", hin, cfg.num_experts, cfg.expert_capacity, return_routing=True)
+        taps["route::" + p] = m
+    else:
+        ff = ec_moe(sd, p + ".mlp", hin, cfg.num_experts, cfg.expert_capacity) if spec.moe else swiglu(sd, p + ".mlp", hin)
+    out = x + g_m.unsqueeze(1) * ff
+    if taps is not None:
+        taps["out::" + p] = out.detach()
+    return out
 
 
 def get_mask(noise: Tensor, mask_ratio: float):
@@ -303,7 +311,7 @@ def dit_forward(sd: SD, cfg: RefConfig, x: Tensor, t: Tensor, y: Tensor, mask_ra
     else:
         y_mixer = yy
     for spec in mixer:
-        h = dit_block(sd, spec, cfg, h, y_mixer, c)
+        h = dit_block(sd, spec, cfg, h, y_mixer, c, taps)
     if taps is not None:
         taps["mixer_out"] = h
     mask = ids_restore = None
@@ -315,7 +323,7 @@ def dit_forward(sd: SD, cfg: RefConfig, x: Tensor, t: Tensor, y: Tensor, mask_ra
     if "patch_mixer_map_xout.1.weight" in sd:
         h = _lin(sd, "patch_mixer_map_xout.1", _ln_w(sd, "patch_mixer_map_xout.0", h, eps))
     for spec in blocks:
-        h = dit_block(sd, spec, cfg, h, yy, c)
+        h = dit_block(sd, spec, cfg, h, yy, c, taps)
     if taps is not None:
         taps["backbone_out"] = h
     shift, scale = _lin(sd, "final_layer.adaLN_modulation.1", _gelu_tanh(c)).chunk(2, dim=1)
@@ -329,7 +337,7 @@ def dit_forward(sd: SD, cfg: RefConfig, x: Tensor, t: Tensor, y: Tensor, mask_ra
 # ------------------------------------------------------------------------------------------- EDM loss
 def edm_loss(sd: SD, cfg: RefConfig, x: Tensor, y: Tensor, rnd_normal: Tensor, eps_noise: Tensor,
              mask_ratio: float, mask_noise: Optional[Tensor], p_mean: float, p_std: float, sigma_data: float = 0.9,
-             return_parts: bool = False):
+             return_parts: bool = False, taps: Optional[dict] = None):
     """model.py:181-210 with the three random draws passed in (order: randn[B,1,1,1], randn_like(x), rand[B,T])."""
     sigma = (rnd_normal.view(-1, 1, 1, 1) * p_std + p_mean).exp()
     weight = (sigma ** 2 + sigma_data ** 2) / (sigma * sigma_data) ** 2
@@ -338,7 +346,7 @@ def edm_loss(sd: SD, cfg: RefConfig, x: Tensor, y: Tensor, rnd_normal: Tensor, e
     c_out = sigma * sigma_data / (sigma ** 2 + sigma_data ** 2).sqrt()
     c_in = 1 / (sigma_data ** 2 + sigma ** 2).sqrt()
     c_noise = sigma.log() / 4
-    Fx, mask = dit_forward(sd, cfg, c_in * xn, c_noise.flatten(), y, mask_ratio, mask_noise)
+    Fx, mask = dit_forward(sd, cfg, c_in * xn, c_noise.flatten(), y, mask_ratio, mask_noise, taps=taps)
     D = c_skip * xn + c_out * Fx
     loss = weight * (D - x) ** 2
     if mask_ratio > 0:
@@ -351,13 +359,13 @@ def edm_loss(sd: SD, cfg: RefConfig, x: Tensor, y: Tensor, rnd_normal: Tensor, e
     return out
 
 
-def latent_diffusion_forward(sd, cfg, batch, rnd_normal, eps_noise, mask_noise, mask_ratio, p_mean, p_std):
+def latent_diffusion_forward(sd, cfg, batch, rnd_normal, eps_noise, mask_noise, mask_ratio, p_mean, p_std, taps=None):
     """LatentDiffusion.forward for precomputed latents (model.py:104-142): caption drop then fp32 casts."""
     lat = batch["image_latents"].float()
     cond = batch["caption_latents"].float()
     if "drop_caption_mask" in batch:
         cond = cond * batch["drop_caption_mask"].view(-1, 1, 1, 1).float()
-    return edm_loss(sd, cfg, lat, cond, rnd_normal, eps_noise, mask_ratio, mask_noise, p_mean, p_std)
+    return edm_loss(sd, cfg, lat, cond, rnd_normal, eps_noise, mask_ratio, mask_noise, p_mean, p_std, taps=taps)
 
 
 # ------------------------------------------------------------------------------------------- optimiser side

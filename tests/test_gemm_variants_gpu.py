@@ -24,7 +24,7 @@ def _operand(rows, k, kcontig, scale=1.0):
 
 def _run(hip, variant, **kw):
     rc = hip.gemm(variant=hip.GEMM_VARIANT_NAMES[variant], expect=None, **kw)
-    if rc == -1:
+    if rc == hip.NOT_ELIGIBLE:
         return False
     hip.check(rc, "md_gemm_bf16")
     torch.cuda.synchronize()
@@ -155,11 +155,11 @@ def test_pp256_refuses_what_it_cannot_run(hip):
     B = torch.zeros(256, 192, device=dev, dtype=torch.bfloat16)
     C = torch.zeros(256, 256, device=dev, dtype=torch.bfloat16)
     # K = 192 is not a multiple of 128; atomics; an activation it has no instantiation for
-    assert hip.gemm(A, B, C, 256, 256, 192, lda=192, ldb=192, ldc=256, variant=hip.GEMM_PP256, expect=None) == -1
+    assert hip.gemm(A, B, C, 256, 256, 192, lda=192, ldb=192, ldc=256, variant=hip.GEMM_PP256, expect=None) == hip.NOT_ELIGIBLE
     Cf = torch.zeros(256, 256, device=dev)
     assert hip.gemm(A, B, Cf, 256, 256, 128, lda=192, ldb=192, ldc=256, mode=hip.EPI_ATOMIC_F32, ksplit=1,
-                    variant=hip.GEMM_PP256, expect=None) == -1
-    assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, act=hip.ACT_SILU, variant=hip.GEMM_PP256, expect=None) == -1
+                    variant=hip.GEMM_PP256, expect=None) == hip.NOT_ELIGIBLE
+    assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, act=hip.ACT_SILU, variant=hip.GEMM_PP256, expect=None) == hip.NOT_ELIGIBLE
     assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, variant=99, expect=None) == -1
 
 

@@ -427,6 +427,58 @@ def test_edm_patchify_loss(hip, masked):
     close(lps, lp, rel=1e-4, what="loss per sample")
     close(lmean, lp.mean().view(1), rel=1e-4, what="loss mean")
     close(dtok, tr.grad, rel=1e-3, what="dtok")
+    # ---- the training-step forms: fp16 latents in (fp32 copy out), bf16 dL/dF pre-multiplied by the microbatch weight, loss
+    # accumulated on the device; and the batch mean is a fixed-order sum (bit-identical from run to run)
+    x0h = x0.half()
+    xn2, x0f = torch.empty_like(x0), torch.empty_like(x0)
+    hip.check(L.md_edm_prepare_f16(x0h.data_ptr(), eps.data_ptr(), rnd.data_ptr(), xn2.data_ptr(), x0f.data_ptr(), sigma.data_ptr(),
+                                   cin.data_ptr(), cnoise.data_ptr(), B, C * H * W, -0.6, 1.2, 0.9, st), "prepare_f16")
+    torch.cuda.synchronize()
+    assert torch.equal(x0f, x0h.float())
+    close(xn2, x0h.float() + eps * s.view(-1, 1, 1, 1), rel=1e-6, what="xn from fp16 latents")
+    w = 0.375
+    dtb = torch.empty(B * Tk, C * p * p, device=DEV, dtype=torch.bfloat16)
+    lps2, lmean2, acc = torch.empty(B, device=DEV), torch.empty(1, device=DEV), torch.full((1,), 2.0, device=DEV)
+    hip.check(L.md_edm_loss_train(tok.data_ptr(), keep.data_ptr() if masked else None, xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(),
+                                  lps2.data_ptr(), lmean2.data_ptr(), dtb.data_ptr(), w, acc.data_ptr(), w, B, Tk, C, H, W, p, 0.9, st), "loss_train")
+    torch.cuda.synchronize()
+    assert torch.equal(lps2, lps) and torch.equal(lmean2, lmean)
+    assert abs(acc.item() - (2.0 + w * lmean.item())) <= 1e-6 * abs(acc.item())
+    close(dtb, (dtok * w).bfloat16(), rel=1e-6, what="bf16 dtok pre-scaled by the microbatch weight")
+    for _ in range(3):
+        lm = torch.empty(1, device=DEV)
+        hip.check(L.md_edm_loss(tok.data_ptr(), keep.data_ptr() if masked else None, xn.data_ptr(), x0.data_ptr(), sigma.data_ptr(),
+                                lps2.data_ptr(), lm.data_ptr(), None, B, Tk, C, H, W, p, 0.9, st), "loss")
+        torch.cuda.synchronize()
+        assert torch.equal(lm, lmean), "the batch-mean loss must not depend on arrival order"
+
+
+def test_gemm_operand_lists(hip):
+    """md_gemm_args.A_list / B_list (pp256, fp32 slices): every (batch, split) item reads its own operand pair; with
+    md_splitk_reduce the launch computes sum_l A_l B_l -- the grouped adaLN condition-vector gradient (28 layers x 2 k-parts)."""
+    torch.manual_seed(9)
+    L, st = hip.lib(), hip.stream_ptr()
+    Bm, D, N, G, parts = 256, 1024, 1536, 5, 2
+    kspan = N // parts
+    dm = bf(torch.randn(G, Bm, N, device=DEV))
+    Ws = [bf(torch.randn(N, D, device=DEV) / math.sqrt(N)) for _ in range(G)]            # separate allocations on purpose
+    al = torch.tensor([dm[i].data_ptr() + 2 * c * kspan for i in range(G) for c in range(parts)], dtype=torch.int64).to(DEV)
+    bl = torch.tensor([Ws[i].data_ptr() + 2 * c * kspan * D for i in range(G) for c in range(parts)], dtype=torch.int64).to(DEV)
+    ks = G * parts
+    ws = torch.empty(ks, Bm, D, device=DEV)
+    chosen = []
+    hip.gemm(A=dm, B=Ws[0], C=ws, M=Bm, N=D, K=kspan * ks, lda=N, ldb=D, ldc=D, sC=ks * Bm * D, sSplit=Bm * D, ksplit=ks,
+             a_kcontig=1, b_kcontig=0, mode=hip.EPI_STORE_F32, A_list=al, B_list=bl, chosen=chosen)
+    out = torch.full((Bm, D), 1.0, device=DEV)
+    hip.check(L.md_splitk_reduce(ws.data_ptr(), out.data_ptr(), Bm, D, D, 0, ks, 1, 1, st), "reduce")
+    torch.cuda.synchronize()
+    assert chosen == [hip.GEMM_PP256]
+    ref = 1.0 + sum(dm[i].float() @ Ws[i].float() for i in range(G))
+    close(out, ref, rel=2e-3, what="sum over operand-list items")
+    # lists on a kernel that is not built for them are refused as a bad argument, not silently ignored
+    C = torch.empty(Bm, D, device=DEV, dtype=torch.bfloat16)
+    assert hip.gemm(A=dm, B=Ws[0], C=C, M=Bm, N=D, K=kspan, lda=N, ldb=D, ldc=D, a_kcontig=1, b_kcontig=0, A_list=al, B_list=bl,
+                    expect=None) == -1
 
 
 # ------------------------------------------------------------------------------------------------ optimiser
@@ -522,7 +574,7 @@ def test_moe_layer_with_oracle_routing(hip, variant, B, S, d, f):
 
     def gemm(**kw):
         rc = hip.gemm(variant=v, expect=None, **kw)
-        if rc == -1:
+        if rc == hip.NOT_ELIGIBLE:
             rc = hip.gemm(variant=hip.GEMM_AUTO, expect=None, **kw)
         hip.check(rc, "gemm")
     gemm(A=xin, B=w1, C=hact, C2=hpre, M=Bk, N=f, K=d, lda=d, ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f, sC2=Bk * f,

@@ -122,22 +122,30 @@ def test_sampler_matches_reference(tag, guidance):
     assert (x - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
-def test_xl2_forward_matches_reference():
-    """BASELINE.json configs[1] geometry (MicroDiT_XL_2, dit.py:671-709: head_dim 64, per-layer head counts 8..16, FFN hidden
-    512..3840, 8 experts): loss, raw network output and mask of the oracle vs the reference's own run (tests/golden/xl2_mask75.npz,
-    oracle/gen_golden.py xl2).  Forward only — the 478 gradient norms of the same fixture are checked on the GPU box by
-    tests/test_engine_gpu.py::test_xl2_train_step_parity through the oracle's backward."""
-    z = np.load(os.path.join(G, "xl2_mask75.npz"))
-    cfg = orc.xl2_config()
-    sd = orc.synth_state_dict(cfg, 41)
-    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 2, 42)
+XL2_CASES = [("xl2_mask75", dict(), 2, 41, 0.75, -0.6, 1.2),                                          # configs/res_256_pretrain.yaml
+             ("xl2_mask0", dict(), 2, 43, 0.0, -0.6, 1.2),                                            # configs/res_256_finetune.yaml
+             ("xl2_res512_mask75", dict(input_size=64, pos_interp_scale=2.0), 1, 45, 0.75, 0.0, 0.6)]   # configs/res_512_pretrain.yaml
+
+
+@pytest.mark.parametrize("tag,ckw,B,seed,ratio,pm,ps", XL2_CASES)
+def test_xl2_forward_matches_reference(tag, ckw, B, seed, ratio, pm, ps):
+    """BASELINE.json configs[1], [3], [4] geometries at XL/2 widths (MicroDiT_XL_2, dit.py:671-709: head_dim 64, per-layer head
+    counts 8..16, FFN hidden 512..3840, 8 experts; mask 0.75 / mask 0 at 32 x 32 latents, and 64 x 64 latents with
+    pos_interp_scale 2): loss, raw network output and mask of the oracle vs the reference's own run (tests/golden/<tag>.npz,
+    oracle/gen_golden.py xl2 / xl2_mask0 / xl2_res512).  Forward only — the 476 gradient norms of the same fixtures are checked
+    on the GPU box by tests/test_engine_gpu.py::test_xl2_train_step_parity through the oracle's backward."""
+    z = np.load(os.path.join(G, tag + ".npz"))
+    cfg = orc.xl2_config(**ckw)
+    sd = orc.synth_state_dict(cfg, seed)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1)
     with torch.no_grad():
-        loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, 0.75, -0.6, 1.2)
+        loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, ratio, pm, ps)
         assert abs(loss.item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
-        sigma = (rnd * 1.2 - 0.6).exp()
+        sigma = (rnd * ps + pm).exp()
         xin = (batch["image_latents"].float() + epsn * sigma) / (0.9 ** 2 + sigma ** 2).sqrt()
         cond = batch["caption_latents"].float() * batch["drop_caption_mask"].view(-1, 1, 1, 1)
-        sample, mask = orc.dit_forward(sd, cfg, xin, (sigma.log() / 4).flatten(), cond, 0.75, mnoise)
+        sample, mask = orc.dit_forward(sd, cfg, xin, (sigma.log() / 4).flatten(), cond, ratio, mnoise)
     assert np.abs(sample.numpy() - z["sample"]).max() <= 1e-4 * np.abs(z["sample"]).max()
-    assert np.array_equal(mask.numpy(), z["mask"])
+    if ratio > 0:
+        assert np.array_equal(mask.numpy(), z["mask"])
     assert len(z["grad_keys"]) == 476          # 478 state_dict entries minus the two buffers

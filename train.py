@@ -110,13 +110,17 @@ def train(cfg: dict):
     if eval_every and ds.get("eval"):
         eval_loader = mdcfg.instantiate(ds["eval"], image_size=ds["image_size"], batch_size=ds["eval_batch_size"] // world,
                                         cap_seq_size=seq, cap_emb_dim=emb, loop=False)
+    trainer.sync_replicas()        # rank 0's weights / moments everywhere (same-seed init and resume make them equal already)
+    check_every = int(cfg.get("misc", {}).get("replica_check_interval", 500))
     t_last = time.time()
     for step, batch in zip(range(start, max_ba), loader):
         loss = trainer.train_step(batch)
         if eval_loader is not None and (step + 1) % eval_every == 0:
-            ev = evaluate(model, eval_loader, world)
+            ev = evaluate(model, eval_loader, world, microbatch=trainer.microbatch_size, opt=opt)
             if rank == 0:
                 print(json.dumps({"batch": step + 1, "metrics/eval/loss": ev}), flush=True)
+        if world > 1 and check_every and (step + 1) % check_every == 0 and not trainer.replicas_in_sync():
+            raise RuntimeError(f"data-parallel replicas diverged at batch {step + 1} (weight checksums differ across ranks)")
         if not torch.isfinite(loss):                               # NaNCatcher (callbacks.py:47-64)
             raise RuntimeError(f"Train loss contains a NaN at batch {step}")
         if rank == 0 and (step + 1) % log_every == 0:
@@ -127,7 +131,11 @@ def train(cfg: dict):
         if rank == 0 and folder and save_every and (step + 1) % save_every == 0:
             os.makedirs(folder, exist_ok=True)
             tmp = os.path.join(folder, "latest.pt.tmp")
-            torch.save({"state": {"model": {"dit." + k: v for k, v in model.dit.state_dict().items()}},
+            ema_sd = opt.ema_state_dict()
+            state = {"model": {"dit." + k: v for k, v in model.dit.state_dict().items()}}
+            if ema_sd is not None:                                  # the EMA weights as a loadable model state (evaluation / export)
+                state["ema_model"] = {"dit." + k: v for k, v in ema_sd.items()}
+            torch.save({"state": state,
                         "optimizer": opt.state_dict(), "batch": step + 1, "rng_cuda": torch.cuda.get_rng_state(),
                         "loader": loader.state_dict() if hasattr(loader, "state_dict") else None}, tmp)
             os.replace(tmp, os.path.join(folder, "latest.pt"))      # never leave a truncated latest.pt behind
@@ -135,15 +143,33 @@ def train(cfg: dict):
 
 
 @torch.no_grad()
-def evaluate(model, eval_loader, world: int) -> float:
+def evaluate(model, eval_loader, world: int, microbatch: int = 0, opt=None) -> float:
     """Composer's eval loop around LatentDiffusion.eval_forward / DistLoss (model.py:217-229, utils.py:598-614): the EDM loss
-    at eval_mask_ratio = 0 (every token kept) averaged over the eval batches of all ranks."""
+    at eval_mask_ratio = 0 (every token kept) averaged over the eval batches of all ranks.  Like Composer, the rank batch is
+    evaluated in slices of device_train_microbatch_size (at mask 0 a slice has 4x the backbone tokens of a training
+    microbatch), each slice weighted by its share, and the EMA weights (once they exist) are the ones evaluated."""
     was_training = model.training
     model.eval()
     metric = model.get_metrics(is_train=False)["loss"]
-    for batch in eval_loader:
-        model.update_metric(batch, model.eval_forward(batch), metric)
-    model.train(was_training)
+    key = model.image_latents_key
+    swap = opt.swap_ema() if opt is not None else None
+    if swap is not None:
+        swap.__enter__()
+    try:
+        for batch in eval_loader:
+            n = batch[key].shape[0] if key in batch else next(v.shape[0] for v in batch.values() if torch.is_tensor(v))
+            mb = n if microbatch <= 0 else min(microbatch, n)
+            loss = None
+            for s in range(0, n, mb):
+                part = {k: (v[s:s + mb] if torch.is_tensor(v) and v.shape[0] == n else v) for k, v in batch.items()}
+                w = min(mb, n - s) / n
+                l = model.eval_forward(part)[0] * w
+                loss = l if loss is None else loss + l
+            model.update_metric(batch, (loss, None, None), metric)
+    finally:
+        if swap is not None:
+            swap.__exit__(None, None, None)
+        model.train(was_training)
     tot = torch.stack([torch.as_tensor(metric.loss, dtype=torch.float32, device="cuda").reshape(()),
                        torch.tensor(float(metric.batches), device="cuda")])
     if world > 1:
