@@ -1,0 +1,57 @@
+#!/bin/bash
+# ONE parametrised runner for gpurun calls (replaces the 33 one-shot scripts of round 2; what each call of a round ran and
+# where its output went is indexed in profiles/CALLS.md).  Usage, from the build container:
+#
+#   gpurun --timeout 900 -- 'bash scripts/gpu_call.sh <tag> <step> [<step> ...]'
+#
+# Steps (each writes gpurun_out/<tag>_<step>.log; steps run in the order given):
+#   tests[:<pytest -k expr>]   python -m pytest tests -m gpu -q [-k expr]
+#   testfile:<path>[:<k>]      one test file
+#   bench[:<extra flags>]      python bench.py <flags>          (last line -> gpurun_out/<tag>_bench.json)
+#   stats[:<bench flags>]      rocprofv3 --kernel-trace --stats around bench.py (summary -> gpurun_out/<tag>_kernel_stats.txt)
+#   ab[:<args>]                python scripts/ab_step.py <args> (same-process A/B of engine options)
+#   traffic                    the two PMC passes of scripts/pmc_workload.py + scripts/pmc_traffic.py -> gpurun_out/<tag>_gemm_traffic.json
+#   py:<script and args>       python <script and args>
+# Colons separate the step name from its argument; spaces inside an argument must be written as '+'.
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out; export TMPDIR=/tmp
+tag=$1; shift
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}; arg=${arg//+/ }
+  log=gpurun_out/${tag}_${name}.log
+  echo "=== $step"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout -k 10 1500 python -m pytest tests -m gpu -q -x -k "$arg" > "$log" 2>&1
+      else timeout -k 10 1500 python -m pytest tests -m gpu -q > "$log" 2>&1; fi
+      tail -n 15 "$log" ;;
+    testfile)
+      f=${arg%%:*}; k=""; [[ "$arg" == *:* ]] && k=${arg#*:}
+      log=gpurun_out/${tag}_$(basename "$f" .py).log
+      if [ -n "$k" ]; then timeout -k 10 1500 python -m pytest "$f" -m gpu -q -x -k "$k" > "$log" 2>&1
+      else timeout -k 10 1500 python -m pytest "$f" -m gpu -q -x > "$log" 2>&1; fi
+      tail -n 12 "$log" ;;
+    bench)
+      timeout -k 10 900 python bench.py $arg > "$log" 2>&1
+      tail -n 1 "$log" > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json ;;
+    stats)
+      flags=${arg:---steps 3 --warmup 1 --no-cpu-baseline --no-other-stages --no-profile}
+      ( cd /tmp && timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$tag" -- \
+          python "$GRAFT_REPO_ROOT/bench.py" $flags > "$GRAFT_REPO_ROOT/$log" 2>&1 )
+      python scripts/rocpd_stats.py "gpurun_out/prof_$tag" "$flags" > gpurun_out/${tag}_kernel_stats.txt 2>&1
+      head -n 40 gpurun_out/${tag}_kernel_stats.txt
+      find "gpurun_out/prof_$tag" -type f ! -name "*stats*" -size +1M -delete 2>/dev/null ;;
+    ab)
+      timeout -k 10 900 python scripts/ab_step.py $arg > "$log" 2>&1; cat "$log" | grep -v "^$" | tail -n 40 ;;
+    traffic)
+      ( cd /tmp && timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_fetch_$tag" -- \
+          python "$GRAFT_REPO_ROOT/scripts/pmc_workload.py" > "$GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_fetch.log" 2>&1 )
+      ( cd /tmp && timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_write_$tag" -- \
+          python "$GRAFT_REPO_ROOT/scripts/pmc_workload.py" > "$GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_write.log" 2>&1 )
+      python scripts/pmc_traffic.py "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" "gpurun_out/${tag}_gemm_traffic.json" 2>&1 | tail -n 8
+      find "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" -type f -size +1M -delete 2>/dev/null ;;
+    py)
+      timeout -k 10 900 python $arg > "$log" 2>&1; tail -n 40 "$log" ;;
+    *) echo "unknown step $name" ;;
+  esac
+done
