@@ -71,13 +71,17 @@ typedef struct md_gemm_args {
                                {t_entry, t_prologue_done, t_loop_done, t_stores_drained (shader clock), wall clock
                                (100 MHz), XCC_ID << 32 | HW_ID, 0, 0} at timeline[linear_workgroup_id * 8] */
     int32_t* chosen_variant; /* optional HOST pointer: receives the md_gemm_variant that was actually launched */
-    /* Operand lists (PP256 only; NULL = the strided form above).  DEVICE arrays of batch * ksplit device pointers: item
-     * (batch b, split s) reads A_list[b * ksplit + s] / B_list[b * ksplit + s] as ITS operand for a contraction of length
-     * K / ksplit starting at element 0 -- i.e. a "split" is then a separate operand pair whose products are summed by
-     * md_splitk_reduce (the adaLN condition-vector gradient: sum over 28 layers of dmod_l W_l in ONE launch), and a "batch"
-     * a separate problem of the same shape. */
+    /* Operand lists (PP256 fp32-slice kernels only; NULL = the strided form above).  DEVICE arrays of
+     * batch * ksplit * list_segments device pointers.  Item (batch b, split s) contracts, in order, the list_segments operand
+     * pairs A_list[i] / B_list[i], i = (b * ksplit + s) * list_segments + j, each over K / (ksplit * list_segments) elements
+     * starting at its element 0, accumulating all of them in registers before its one fp32 slice is written:
+     *   list_segments = 1, ksplit = G : G separate operand pairs whose products md_splitk_reduce sums (the adaLN
+     *                                   condition-vector gradient: sum over the layers of dmod_l W_l in ONE launch);
+     *   list_segments = G, ksplit = 1 : ONE contraction over the concatenation of G operand pairs (the caption-token gradient
+     *                                   sum_l dkv_l Wkv_l of all 28 blocks: no slices, no reduction pass). */
     const void* const* A_list;
     const void* const* B_list;
+    int32_t list_segments;   /* 0 or 1 = one pair per item */
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot
@@ -133,13 +137,15 @@ typedef struct md_ln_bwd_args {
 int md_ln_fwd(const md_ln_args* a, hipStream_t stream);
 int md_ln_bwd(const md_ln_args* a, const md_ln_bwd_args* b, hipStream_t stream);
 
-/* Non-parametric LayerNorm over columns [col0, col0 + width) of every row of buf, in place; rstd saved.
+/* Non-parametric LayerNorm over nseg column segments of every row of buf, in place: segment s covers columns
+ * [col0 + s * seg_stride, ... + width); rstd_out is [nseg][rows].  nseg = 2, seg_stride = hidden normalises the q and the k
+ * half of a packed qkv row in one launch.
  * (ln_q / ln_k over ALL heads concatenated: utils.py:113-114,122-125,175-176,183-186.) */
-int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, float* rstd_out, float eps,
-                hipStream_t stream);
-/* d: grad buffer (in place, dy -> dx); y: the normalised forward output. */
+int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, int32_t nseg, int64_t seg_stride,
+                float* rstd_out, float eps, hipStream_t stream);
+/* d: grad buffer (in place, dy -> dx); y: the normalised forward output; same segment addressing in both. */
 int md_qkln_bwd(void* d, int64_t ldd, int64_t dcol0, const void* y, int64_t ldy, int64_t ycol0, int64_t rows,
-                int64_t width, const float* rstd, hipStream_t stream);
+                int64_t width, int32_t nseg, int64_t dseg_stride, int64_t yseg_stride, const float* rstd, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- attention */
 /* softmax(scale * Q K^T) V per (batch, head), non-causal, no mask.  Row r of head h of batch b of X lives at
@@ -179,6 +185,9 @@ int md_act_fwd(const void* x, void* y, int64_t n, int32_t act, hipStream_t strea
 int md_act_bwd(const float* dy, const void* x, void* dx, int64_t n, int32_t act, hipStream_t stream); /* dx = dy*act'(x) */
 int md_colsum(const void* x, int32_t x_is_f32, int64_t ld, float* out, int64_t rows, int64_t C, hipStream_t stream); /* out += */
 int md_cast_f32_bf16(const float* x, void* y, int64_t n, const float* scale_ptr, hipStream_t stream);
+/* y = bf16(x), x = 0: stages one bucket of the fp32 gradient accumulators for the data-parallel exchange and clears it in the
+ * same pass (the reduce-scatter form of FSDP's gradient reduction, configs/res_256_pretrain.yaml:117-118 SHARD_GRAD_OP). */
+int md_cast_f32_bf16_clear(float* x, void* y, int64_t n, hipStream_t stream);
 /* y(bf16)[r, :] = x[r, :] * rowscale[r / rows_per_sample]; x_dtype 0 = f16, 1 = f32 (caption cast + drop, model.py:132-139) */
 int md_cast_rows_bf16(const void* x, int32_t x_dtype, void* y, int64_t rows, int64_t C, const float* rowscale,
                       int64_t rows_per_sample, hipStream_t stream);

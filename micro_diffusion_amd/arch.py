@@ -206,3 +206,17 @@ def sincos_table(dim: int, grid: int, pos_interp_scale: float) -> np.ndarray:
         ang = np.outer(pos, freq)
         halves.append(np.concatenate([np.sin(ang), np.cos(ang)], axis=1))
     return np.concatenate(halves, axis=1)
+
+
+def bucket_key(name: str, ndim: int = 2) -> str:
+    """Data-parallel bucket a parameter belongs to: one per DiT block ("blocks.17", "patch_mixer.3"), "final_layer", "rest"
+    (embedders, caption block, mixer maps) -- the segments whose backward finishes together (engine.backward's on_segment
+    hand-off) -- and "small" for every one-dimensional tensor (biases, LayerNorm weights): those live in one region at the end of
+    the flat buffers, are exchanged as one all-reduce and updated by every rank (the engine reads them from the fp32 masters,
+    so every replica must hold them exactly; the sharded optimiser step only owns slices of the matrix-shaped buckets)."""
+    if ndim <= 1:
+        return "small"
+    top = name.split(".")
+    if top[0] in ("blocks", "patch_mixer") and len(top) > 1 and top[1].isdigit():
+        return ".".join(top[:2])
+    return "final_layer" if top[0] == "final_layer" else "rest"

@@ -159,6 +159,22 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* x, bf16
     }
 }
 
+// y = bf16(x); x = 0: the data-parallel exchange stages a bucket of the fp32 gradient accumulators as bf16 and hands the
+// accumulators back cleared in the same pass (with a sharded optimiser step no later kernel visits the whole accumulator)
+__global__ __launch_bounds__(256) void cast_f32_bf16_clear_kernel(float* x, bf16* y, int64_t n8) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 d0 = *reinterpret_cast<const float4*>(x + i * 8);
+        const float4 d1 = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+        bf16x8 o;
+        o[0] = f2bf(d0.x); o[1] = f2bf(d0.y); o[2] = f2bf(d0.z); o[3] = f2bf(d0.w);
+        o[4] = f2bf(d1.x); o[5] = f2bf(d1.y); o[6] = f2bf(d1.z); o[7] = f2bf(d1.w);
+        st_bf16x8(y + i * 8, o);
+        *reinterpret_cast<float4*>(x + i * 8) = z;
+        *reinterpret_cast<float4*>(x + i * 8 + 4) = z;
+    }
+}
+
 // out(bf16)[row, :] = in[row, :] * rowscale[row / rows_per_sample];  IN = _Float16 or float
 template <typename IN>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const IN* x, bf16* y, int64_t rows, int64_t C,
@@ -283,6 +299,13 @@ extern "C" int md_colsum(const void* x, int32_t x_is_f32, int64_t ld, float* out
 extern "C" int md_cast_f32_bf16(const float* x, void* y, int64_t n, const float* scale_ptr, hipStream_t st) {
     if (!x || !y || n <= 0 || n % 8) return MD_BAD_ARG;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, st, x, (bf16*)y, n / 8, scale_ptr);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_cast_f32_bf16_clear(float* x, void* y, int64_t n, hipStream_t st) {
+    if (!x || !y || n <= 0 || n % 8) return MD_BAD_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_clear_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, st, x, (bf16*)y, n / 8);
     MD_LAUNCH_CHECK();
     return 0;
 }

@@ -265,22 +265,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     bool s_live = true;
     const char *sA = nullptr, *sB = nullptr;       // uniform base pointers of the stager's current k-tile
     unsigned aofs[2][2], bofs[2][2];
+    int s_m0 = 0, s_n0 = 0, s_li = 0, s_seg_kt = 0;   // operand lists: tile origin, first list index and k-tiles left in the segment
+    auto stager_segment = [&](int li) {            // point the stager at operand pair li of the lists (uniform -> s_load)
+        const bf16* Ab = reinterpret_cast<const bf16*>(p.A_list[li]);
+        const bf16* Bb = reinterpret_cast<const bf16*>(p.B_list[li]);
+        sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)s_m0 * w.lda : Ab + s_m0);
+        sB = reinterpret_cast<const char*>(BKC ? Bb + (int64_t)s_n0 * w.ldb : Bb + s_n0);
+        s_seg_kt = w.nk_seg;
+    };
     auto stager_open = [&](int n) {                // point the stager at item ordinal n
         int m0, n0, batch, split;
         work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
-        int64_t kbeg = (int64_t)split * w.kspan;
-        const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
-        const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
-        if (EPI == PP_E_F32 && p.A_list) {         // operand lists (fp32-slice kernels only: the others are at their register budget): every (batch, split) item names its own operand pair (uniform -> s_load)
-            const int li = __builtin_amdgcn_readfirstlane(batch * w.ksplit + split);
-            Ab = reinterpret_cast<const bf16*>(p.A_list[li]);
-            Bb = reinterpret_cast<const bf16*>(p.B_list[li]);
-            kbeg = 0;
-        }
-        sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)m0 * w.lda + kbeg : Ab + kbeg * w.lda + m0);
-        sB = reinterpret_cast<const char*>(BKC ? Bb + (int64_t)n0 * w.ldb + kbeg : Bb + kbeg * w.ldb + n0);
         stage_offsets<AKC>(aofs, m0, w.M, w.lda, wave, lane);
         stage_offsets<BKC>(bofs, n0, w.N, w.ldb, wave, lane);
+        if (EPI == PP_E_F32 && p.A_list) {         // operand lists (fp32-slice kernels only: the others are at their register budget)
+            s_m0 = m0;
+            s_n0 = n0;
+            s_li = __builtin_amdgcn_readfirstlane((batch * w.ksplit + split) * w.nseg);
+            stager_segment(s_li);
+            return;
+        }
+        const int64_t kbeg = (int64_t)split * w.kspan;
+        const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+        const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+        sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)m0 * w.lda + kbeg : Ab + kbeg * w.lda + m0);
+        sB = reinterpret_cast<const char*>(BKC ? Bb + (int64_t)n0 * w.ldb + kbeg : Bb + kbeg * w.ldb + n0);
     };
     auto stager_advance = [&]() {                  // after the last half-tile (A1) of a k-tile
         sA += a_kstep;
@@ -289,6 +298,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             s_kt = 0;
             if (++s_n < w_count) stager_open(s_n);
             else s_live = false;
+        } else if (EPI == PP_E_F32 && p.A_list && --s_seg_kt == 0) {
+            stager_segment(++s_li);                // the item goes on with the next operand pair of its list (same accumulators)
         }
     };
     // KIND: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (the order they are consumed in); BUF = k-tile parity
@@ -552,6 +563,7 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     if (kspan < 128 || kspan % 128) return false;
     if (a->N % 8) return false;                                  // 16-byte column chunks everywhere
     if ((a->A_list || a->B_list) && epi != PP_E_F32) return false;   // operand lists are built into the fp32-slice kernels only
+    if (a->A_list && a->list_segments > 1 && (kspan % ((int64_t)a->list_segments * 128))) return false;   // whole k-tile pairs per segment
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
     if ((epi == PP_E_RES || epi == PP_E_DACT_GELU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
         return false;                                            // only the PLAIN form of these two epilogues is built

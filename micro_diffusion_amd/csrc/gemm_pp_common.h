@@ -126,6 +126,7 @@ struct PPPlan {
     int M, N, ksplit;
     int lda, ldb;
     int rps_shift;                 // log2(rows_per_sample) when that is a power of two, else -1 (gated residual only)
+    int nseg, nk_seg;              // operand lists: segments per item and k-tiles per segment (nseg <= 1: one operand pair per item)
 };
 
 __device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
@@ -328,6 +329,8 @@ inline bool md_gemm_pp_plan(const md_gemm_args* a, PPPlan* w) {
     w->total = (int)total;
     w->kspan = (int)(a->K / a->ksplit);
     w->nk = w->kspan / BKT;
+    w->nseg = (a->A_list && a->list_segments > 1) ? a->list_segments : 1;
+    w->nk_seg = w->nk / w->nseg;
     w->group_n = a->raster_group_n > 0 ? a->raster_group_n : 1;
     w->M = (int)a->M;
     w->N = (int)a->N;

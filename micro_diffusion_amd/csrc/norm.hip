@@ -311,19 +311,23 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(float* dS, int64_t l
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void qkln_fwd_kernel(bf16* buf, int64_t rows, int64_t ld, int64_t col0, int C,
-                                                       float* rstd_out, float eps) {
+__global__ __launch_bounds__(256) void qkln_fwd_kernel(bf16* buf, int64_t rows, int64_t ld, int64_t col0, int C, int nseg,
+                                                       int64_t seg_stride, float* rstd_out, float eps) {
+    // work item vr = row * nseg + seg: segment seg (q, k, ...) of a row starts seg_stride elements after the previous one, so the
+    // q and k halves of a packed qkv row are normalised by ONE launch (they were two, each too short to fill the chip at 16 k rows)
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t items = rows * nseg;
     const float invC = 1.f / (float)C;
+    auto at = [&](int64_t vr) { return buf + (vr / nseg) * ld + col0 + (vr % nseg) * seg_stride; };
     bf16x8 nxt[NCH];
-    if (wave < rows) issue_row<NCH>(buf + wave * ld + col0, C, lane, nxt);
-    for (int64_t row = wave; row < rows; row += nwaves) {
-        bf16* r = buf + row * ld + col0;
+    if (wave < items) issue_row<NCH>(at(wave), C, lane, nxt);
+    for (int64_t vr = wave; vr < items; vr += nwaves) {
+        bf16* r = at(vr);
         float v[NCH][8];
         unpack_row<NCH>(nxt, v);
-        if (row + nwaves < rows) issue_row<NCH>(buf + (row + nwaves) * ld + col0, C, lane, nxt);
+        if (vr + nwaves < items) issue_row<NCH>(at(vr + nwaves), C, lane, nxt);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void qkln_fwd_kernel(bf16* buf, int64_t rows, 
             }
         }
         const float rstd = rsqrtf(wave_sum(q) * invC + eps);
-        if (lane == 0) rstd_out[row] = rstd;
+        if (lane == 0) rstd_out[(vr % nseg) * rows + vr / nseg] = rstd;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane * 8 + j * 512;
@@ -360,20 +364,24 @@ __global__ __launch_bounds__(256) void qkln_fwd_kernel(bf16* buf, int64_t rows, 
 // d (in place) holds dL/dy on entry, dL/dx on exit; y = the normalised values written by the forward.
 template <int NCH>
 __global__ __launch_bounds__(256) void qkln_bwd_kernel(bf16* d, int64_t ldd, int64_t dcol0, const bf16* y, int64_t ldy,
-                                                       int64_t ycol0, int64_t rows, int C, const float* rstd_in) {
+                                                       int64_t ycol0, int64_t rows, int C, int nseg, int64_t dseg_stride,
+                                                       int64_t yseg_stride, const float* rstd_in) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t items = rows * nseg;                      // item vr = row * nseg + seg (see qkln_fwd_kernel)
     const float invC = 1.f / (float)C;
+    auto dat = [&](int64_t vr) { return d + (vr / nseg) * ldd + dcol0 + (vr % nseg) * dseg_stride; };
+    auto yat = [&](int64_t vr) { return y + (vr / nseg) * ldy + ycol0 + (vr % nseg) * yseg_stride; };
     bf16x8 ng[NCH], ny[NCH];
     float nrstd = 0.f;
-    if (wave < rows) {
-        issue_row<NCH>(d + wave * ldd + dcol0, C, lane, ng);
-        issue_row<NCH>(y + wave * ldy + ycol0, C, lane, ny);
-        nrstd = rstd_in[wave];
+    if (wave < items) {
+        issue_row<NCH>(dat(wave), C, lane, ng);
+        issue_row<NCH>(yat(wave), C, lane, ny);
+        nrstd = rstd_in[(wave % nseg) * rows + wave / nseg];
     }
-    for (int64_t row = wave; row < rows; row += nwaves) {
-        bf16* dr = d + row * ldd + dcol0;
+    for (int64_t vr = wave; vr < items; vr += nwaves) {
+        bf16* dr = dat(vr);
         float g[NCH][8], xh[NCH][8];
         unpack_row<NCH>(ng, g);
         unpack_row<NCH>(ny, xh);
@@ -386,10 +394,11 @@ __global__ __launch_bounds__(256) void qkln_bwd_kernel(bf16* d, int64_t ldd, int
                 s1 += g[j][e];
                 s2 += g[j][e] * xh[j][e];
             }
-        if (row + nwaves < rows) {
-            issue_row<NCH>(d + (row + nwaves) * ldd + dcol0, C, lane, ng);
-            issue_row<NCH>(y + (row + nwaves) * ldy + ycol0, C, lane, ny);
-            nrstd = rstd_in[row + nwaves];
+        if (vr + nwaves < items) {
+            const int64_t nx = vr + nwaves;
+            issue_row<NCH>(dat(nx), C, lane, ng);
+            issue_row<NCH>(yat(nx), C, lane, ny);
+            nrstd = rstd_in[(nx % nseg) * rows + nx / nseg];
         }
         s1 = wave_sum(s1) * invC;
         s2 = wave_sum(s2) * invC;
@@ -467,12 +476,13 @@ extern "C" int md_ln_bwd(const md_ln_args* a, const md_ln_bwd_args* b, hipStream
     return 0;
 }
 
-extern "C" int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, float* rstd_out, float eps,
-                           hipStream_t stream) {
-    if (!buf || !rstd_out || rows <= 0 || width <= 0 || width % 8 || width > 64 * 8 * MAXCH || ld % 8 || col0 % 8)
+extern "C" int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, int32_t nseg, int64_t seg_stride,
+                           float* rstd_out, float eps, hipStream_t stream) {
+    if (!buf || !rstd_out || rows <= 0 || width <= 0 || width % 8 || width > 64 * 8 * MAXCH || ld % 8 || col0 % 8 || nseg < 1 ||
+        nseg > 4 || seg_stride % 8 || (nseg > 1 && seg_stride < width))
         return MD_BAD_ARG;
-#define QKF(N) hipLaunchKernelGGL(qkln_fwd_kernel<N>, dim3(ln_grid(rows)), dim3(256), 0, stream, (bf16*)buf, rows, ld, \
-                                  col0, (int)width, rstd_out, eps)
+#define QKF(N) hipLaunchKernelGGL(qkln_fwd_kernel<N>, dim3(ln_grid(rows * nseg)), dim3(256), 0, stream, (bf16*)buf, rows, ld, \
+                                  col0, (int)width, (int)nseg, seg_stride, rstd_out, eps)
     if (width <= 512) QKF(1); else if (width <= 1024) QKF(2); else QKF(4);
 #undef QKF
     MD_LAUNCH_CHECK();
@@ -480,12 +490,13 @@ extern "C" int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, in
 }
 
 extern "C" int md_qkln_bwd(void* d, int64_t ldd, int64_t dcol0, const void* y, int64_t ldy, int64_t ycol0, int64_t rows,
-                           int64_t width, const float* rstd, hipStream_t stream) {
+                           int64_t width, int32_t nseg, int64_t dseg_stride, int64_t yseg_stride, const float* rstd,
+                           hipStream_t stream) {
     if (!d || !y || !rstd || rows <= 0 || width <= 0 || width % 8 || width > 64 * 8 * MAXCH || ldd % 8 || ldy % 8 ||
-        dcol0 % 8 || ycol0 % 8)
+        dcol0 % 8 || ycol0 % 8 || nseg < 1 || nseg > 4 || dseg_stride % 8 || yseg_stride % 8)
         return MD_BAD_ARG;
-#define QKB(N) hipLaunchKernelGGL(qkln_bwd_kernel<N>, dim3(ln_grid(rows)), dim3(256), 0, stream, (bf16*)d, ldd, dcol0, \
-                                  (const bf16*)y, ldy, ycol0, rows, (int)width, rstd)
+#define QKB(N) hipLaunchKernelGGL(qkln_bwd_kernel<N>, dim3(ln_grid(rows * nseg)), dim3(256), 0, stream, (bf16*)d, ldd, dcol0, \
+                                  (const bf16*)y, ldy, ycol0, rows, (int)width, (int)nseg, dseg_stride, yseg_stride, rstd)
     if (width <= 512) QKB(1); else if (width <= 1024) QKB(2); else QKB(4);
 #undef QKB
     MD_LAUNCH_CHECK();

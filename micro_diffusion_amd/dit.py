@@ -14,21 +14,47 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .arch import DiTConfig, ParamSpec, param_table, plan_blocks, sincos_table
+from .arch import DiTConfig, ParamSpec, bucket_key, param_table, plan_blocks, sincos_table
 from .engine import DiTEngine
 
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the fp32 buffers and 128-byte in the bf16 shadow
 
 
+_BUCKET_ALIGN = 1024  # elements; every data-parallel bucket starts (and therefore ends) on a multiple of it, so a bucket splits
+#                       into equal, 128-byte aligned rank chunks for any world size up to 16 (reduce-scatter / all-gather in place)
+
+
 def flat_layout(table):
-    """Offsets (in elements) of every parameter inside the flat buffers: table order, each tensor padded to _ALIGN."""
-    offs, total = {}, 0
-    for spec in table:
-        if spec.buffer:
-            continue
-        offs[spec.name] = total
-        total += ((int(np.prod(spec.shape)) + _ALIGN - 1) // _ALIGN) * _ALIGN
+    """Offsets (in elements) of every parameter inside the flat buffers: matrix-shaped tensors in table order (= the reference's
+    registration order, so the tensors of a block are contiguous and [w1; w2] of a SwiGLU stay adjacent), each padded to _ALIGN,
+    a new data-parallel bucket (arch.bucket_key) starting on a multiple of _BUCKET_ALIGN; then all one-dimensional tensors
+    (the "small" bucket) in one region at the end."""
+    offs, total, prev = {}, 0, None
+    for small in (False, True):
+        for spec in table:
+            if spec.buffer or (len(spec.shape) <= 1) != small:
+                continue
+            key = bucket_key(spec.name, len(spec.shape))
+            if key != prev:
+                total = (total + _BUCKET_ALIGN - 1) // _BUCKET_ALIGN * _BUCKET_ALIGN
+                prev = key
+            offs[spec.name] = total
+            total += ((int(np.prod(spec.shape)) + _ALIGN - 1) // _ALIGN) * _ALIGN
+    total = (total + _BUCKET_ALIGN - 1) // _BUCKET_ALIGN * _BUCKET_ALIGN
     return offs, total
+
+
+def bucket_ranges(table, offs, total):
+    """[(key, lo, hi)] in flat order: maximal runs of one bucket key; the ranges tile [0, total) ("rest" appears several times:
+    front end, mixer maps; "small" is the tail)."""
+    items = sorted(((offs[s.name], bucket_key(s.name, len(s.shape))) for s in table if not s.buffer))
+    out = []
+    for o, key in items:
+        if not out or out[-1][0] != key:
+            if out:
+                out[-1][2] = o
+            out.append([key, o, total])
+    return [tuple(r) for r in out]
 
 
 class _Node(nn.Module):
@@ -186,7 +212,8 @@ class DiT(nn.Module):
             S[spec.name] = flat_s[o:o + n].view(spec.shape)
         buf = {k: v for k, v in self.named_buffers()}
         self._plist = [params[s.name] for s in self._table if not s.buffer]
-        self._flat = {"p": flat_p, "g": flat_g, "s": flat_s, "offs": offs, "total": total, "P": P, "G": G, "S": S}
+        self._flat = {"p": flat_p, "g": flat_g, "s": flat_s, "offs": offs, "total": total, "P": P, "G": G, "S": S,
+                      "buckets": bucket_ranges(self._table, offs, total)}
         self._engine = DiTEngine(self.config, P, S, G, buf)
         self._shadow_version = -1
         self._grad_anchor = torch.zeros(1, device=dev, requires_grad=True)

@@ -109,6 +109,8 @@ class DiTEngine:
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
         self.attn_bwd_prefer = hip.ATTN_BWD_AUTO   # same for the attention backward (md_attn_args.bwd_split)
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
+        self.before_segment = None         # data parallelism: callable(bucket key) run before the first kernel that reads the bf16
+        #                                    weights of a bucket ("rest", block names, "final_layer"): waits for their all-gather
         self.keep_last_tape = False        # tests: keep the most recent forward's tape in self.last_tape (per-block activations)
         self.last_tape = None
         self.route_override = None         # tests: {block name: top-k token indices [B, E, k]} replacing the router's choice
@@ -123,6 +125,7 @@ class DiTEngine:
         self._ptr_cache = {}
         self.ksplit_min_items = 192  # work items a split-K factor must reach (A/B: 128 = the round-2 rule)
         self.splitk_force_pp = False  # A/B: force pp256 for every split-K launch it accepts, whatever the tile count
+        self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
 
@@ -151,13 +154,14 @@ class DiTEngine:
         e1.record()
         kp.setdefault(name, []).append((e0, e1, float(nbytes)))
 
-    def _qkln_fwd(self, ptr, rows, ld, off, width, rstd_ptr):
-        self._prof("qk_layernorm", 4.0 * rows * width, lambda: hip.check(
-            self.L.md_qkln_fwd(ptr, rows, ld, off, width, rstd_ptr, self.cfg.norm_eps, self._st()), "md_qkln_fwd"))
+    def _qkln_fwd(self, ptr, rows, ld, off, width, rstd_ptr, nseg=1):
+        """nseg = 2: the q and the k half (adjacent, `width` apart) of a packed qkv row in one launch; rstd [nseg][rows]."""
+        self._prof("qk_layernorm", 4.0 * rows * width * nseg, lambda: hip.check(
+            self.L.md_qkln_fwd(ptr, rows, ld, off, width, nseg, width, rstd_ptr, self.cfg.norm_eps, self._st()), "md_qkln_fwd"))
 
-    def _qkln_bwd(self, dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr):
-        self._prof("qk_layernorm", 6.0 * rows * width, lambda: hip.check(
-            self.L.md_qkln_bwd(dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr, self._st()), "md_qkln_bwd"))
+    def _qkln_bwd(self, dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr, nseg=1):
+        self._prof("qk_layernorm", 6.0 * rows * width * nseg, lambda: hip.check(
+            self.L.md_qkln_bwd(dptr, ldd, doff, yptr, ldy, yoff, rows, width, nseg, width, width, rstd_ptr, self._st()), "md_qkln_bwd"))
 
     def _attn_fwd(self, a):
         nb = 2.0 * a.hd * (2 * a.Sq + 2 * a.Skv) * a.B * a.H
@@ -334,8 +338,7 @@ class DiTEngine:
         qkv = self.empty(M, 3 * hid)
         self.lin_fwd(xin, pre + ".qkv", qkv, M, 3 * hid, dim)
         rq = self.empty(2, M, dtype=F32)
-        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq[0].data_ptr())
-        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, hid, hid, rq[1].data_ptr())
+        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq.data_ptr(), nseg=2)
         o = self.empty(M, hid)
         lse = self.empty(B, heads, S, dtype=F32)
         a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
@@ -354,8 +357,7 @@ class DiTEngine:
                            3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
                            dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
         self._attn_bwd(a)
-        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq[0].data_ptr())
-        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, hid, qkv.data_ptr(), 3 * hid, hid, M, hid, t.rq[1].data_ptr())
+        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq.data_ptr(), nseg=2)
         self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim)
         dxin = self.empty(M, dim)
         self.lin_dgrad(dqkv, pre + ".qkv", dxin, M, 3 * hid, dim)
@@ -470,7 +472,7 @@ class DiTEngine:
             slot[:, :, e].scatter_(1, m_idx[:, e, :], torch.arange(k, device=self.dev, dtype=I32).view(1, k).expand(B, k))
         t.slot.copy_(slot.view(B * S, E))
 
-    def _block_bwd(self, bp: BlockPlan, t: Tape, dx, ycond, dycond_f32, B, S, Lc, gc, dgc_f32, group=None):
+    def _block_bwd(self, bp: BlockPlan, t: Tape, dx, ycond, dycond_f32, B, S, Lc, gc, dgc_f32, group=None, kvgroup=None):
         """dx: grad w.r.t. the block output [M, d] (bf16), updated IN PLACE to the grad w.r.t. the block input."""
         L, st, cfg = self.L, self._st(), self.cfg
         d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
@@ -536,7 +538,7 @@ class DiTEngine:
         do2 = self.empty(M, hx)
         self.lin_dgrad(dx, n + ".cross_attn.proj", do2, M, d, hx)
         dq2 = self.empty(M, hx)
-        dkv = self.empty(Mc, 2 * hx)
+        dkv = self.empty(Mc, 2 * hx) if kvgroup is None else kvgroup["buf"][len(kvgroup["w"])]
         delta = self.empty(B, bp.xheads, S, dtype=F32)
         ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, hx,
                             2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
@@ -546,9 +548,14 @@ class DiTEngine:
         self._qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr())
         self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)
         self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
-        # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens
-        self.gemm_f32_acc(out_ptr=dycond_f32.data_ptr(), M=Mc, N=d, K=2 * hx, ldo=d, A=dkv.data_ptr(),
-                          B=self.S[n + ".cross_attn.kv_linear.weight"].data_ptr(), lda=2 * hx, ldb=d, a_kcontig=1, b_kcontig=0)
+        # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens: per block (split-K slices + a
+        # reduction pass into the [B*L, d] fp32 buffer, 28 times), or -- kvgroup -- deferred: dkv of every block is kept and ONE
+        # launch contracts the concatenation [dkv_0 | dkv_1 | ...] with [Wkv_0; Wkv_1; ...] (_dycond_grouped)
+        if kvgroup is None:
+            self.gemm_f32_acc(out_ptr=dycond_f32.data_ptr(), M=Mc, N=d, K=2 * hx, ldo=d, A=dkv.data_ptr(),
+                              B=self.S[n + ".cross_attn.kv_linear.weight"].data_ptr(), lda=2 * hx, ldb=d, a_kcontig=1, b_kcontig=0)
+        else:
+            kvgroup["w"].append(self.S[n + ".cross_attn.kv_linear.weight"].data_ptr())
         dxn2 = self.empty(M, d)
         self.lin_dgrad(dq2, n + ".cross_attn.q_linear", dxn2, M, hx, d)
         a2 = self.ln_args(t.x1, n + ".norm2", None, M, d, mean=t.st2[0], rstd=t.st2[1], rps=S)
@@ -585,6 +592,38 @@ class DiTEngine:
             return
         self.gemm_f32_acc(out_ptr=dgc_f32.data_ptr(), M=B, N=D, K=N, ldo=D, A=dmod.data_ptr(),
                           B=self.S[wname + ".weight"].data_ptr(), lda=N, ldb=D, a_kcontig=1, b_kcontig=0)
+
+    def _dycond_grouped(self, group, Mc, d, K, out_f32):
+        """out[Mc, d] += sum_l dkv_l[Mc, K] @ Wkv_l[K, d] over the G blocks of a group: ONE pp256 launch whose items walk the
+        operand lists segment by segment (md_gemm_args.list_segments) and keep the sum in their accumulators; split over
+        `ks` groups of segments only as far as whole rounds of the 256 CUs need it (a handful of fp32 slices instead of
+        2 x 28)."""
+        G = len(group["w"])
+        if G == 0:
+            return
+        t256 = ((Mc + 255) // 256) * ((d + 255) // 256)
+        if K % 128 or d % 8 or Mc * d > self.ws.numel():
+            for i in range(G):
+                self.gemm_f32_acc(out_ptr=out_f32.data_ptr(), M=Mc, N=d, K=K, ldo=d, A=group["buf"][i].data_ptr(), B=group["w"][i],
+                                  lda=K, ldb=d, a_kcontig=1, b_kcontig=0)
+            return
+        out_us = Mc * d * 4 / 4e6
+        best, best_cost = 1, None
+        for ks in range(1, G + 1):
+            if G % ks or ks * Mc * d > self.ws.numel():
+                continue
+            rounds = -(-t256 * ks // 256)
+            cost = rounds * ((G // ks) * K / 64 * 0.45 + 5.0) + (ks + 2) * out_us
+            if best_cost is None or cost < best_cost:
+                best, best_cost = ks, cost
+        ks, S = best, G // best
+        base = group["buf"].data_ptr()
+        al = self._ptr_list([base + 2 * i * Mc * K for i in range(G)])
+        bl = self._ptr_list(group["w"])
+        self._gemm(A=base, B=group["w"][0], A_list=al.data_ptr(), B_list=bl.data_ptr(), list_segments=S, C=self.ws.data_ptr(), M=Mc, N=d,
+                   K=K * G, lda=K, ldb=d, ldc=d, sC=ks * Mc * d, sSplit=Mc * d, batch=1, ksplit=ks, a_kcontig=1, b_kcontig=0,
+                   mode=hip.EPI_STORE_F32, act=0, alpha=1.0)
+        hip.check(self.L.md_splitk_reduce(self.ws.data_ptr(), out_f32.data_ptr(), Mc, d, d, 0, ks, 1, 1, self._st()), "md_splitk_reduce")
 
     def _ptr_list(self, ptrs):
         """Device array of device pointers (md_gemm_args.A_list / B_list); cached by value: with the fixed-address arenas the
@@ -698,6 +737,8 @@ class DiTEngine:
         C, H, W, p = cfg.in_channels, x_img.shape[-2], x_img.shape[-1], cfg.patch_size
         T, D, Dm = (H // p) * (W // p), cfg.dim, cfg.patch_mixer_dim
         Lc, Dc = y.shape[-2], y.shape[-1]
+        seg = self.before_segment if self.before_segment is not None else (lambda key: None)
+        seg("rest")
         tp = Tape()
         tp.arena = self._arena is not None
         tp.B, tp.T, tp.Lc, tp.H, tp.W = B, T, Lc, H, W
@@ -783,6 +824,7 @@ class DiTEngine:
         tp.ym = ym
         tp.mixer = []
         for bp in self.mixer:
+            seg(bp.name)
             x, bt = self._block_fwd(bp, x, ym, B, T, Lc, gc)
             if self._record:
                 tp.mixer.append(bt)
@@ -815,10 +857,12 @@ class DiTEngine:
             x = xb
         tp.blocks = []
         for bp in self.backbone:
+            seg(bp.name)
             x, bt = self._block_fwd(bp, x, y2, B, Tk, Lc, gc)
             if self._record:
                 tp.blocks.append(bt)
         # ---- final layer, dit.py:513
+        seg("final_layer")
         tp.xlast = x
         tp.fmod = self.empty(B, 2 * D)
         self.lin_fwd(gc, "final_layer.adaLN_modulation.1", tp.fmod, B, 2 * D, D)
@@ -883,6 +927,12 @@ class DiTEngine:
                 grp_b = {"buf": self.empty(len(self.backbone), B, 6 * self.backbone[0].dim), "w": []}
             if self.mixer:
                 grp_m = {"buf": self.empty(len(self.mixer), B, 6 * self.mixer[0].dim), "w": []}
+        kv_b = kv_m = None
+        if self.group_dycond:                       # dkv of every block, kept until the concatenated contraction
+            if self.backbone:
+                kv_b = {"buf": self.empty(len(self.backbone), Mc, 2 * self.backbone[0].xattn_hidden), "w": []}
+            if self.mixer:
+                kv_m = {"buf": self.empty(len(self.mixer), Mc, 2 * self.mixer[0].xattn_hidden), "w": []}
         # ---- final layer
         self.lin_wgrad(dtok, tp.xf, "final_layer.linear", B * Tk, pv, D)
         dxf = self.empty(B * Tk, D)
@@ -898,8 +948,10 @@ class DiTEngine:
         seg("final_layer")
         # ---- backbone
         for bp, bt in zip(reversed(self.backbone), reversed(tp.blocks)):
-            self._block_bwd_scoped(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc, grp_b)
+            self._block_bwd_scoped(bp, bt, dx, tp.y2, dy2_f32, B, Tk, Lc, gc, dgc, grp_b, kv_b)
             seg(bp.name)
+        if kv_b is not None:
+            self._dycond_grouped(kv_b, Mc, self.backbone[0].dim, 2 * self.backbone[0].xattn_hidden, dy2_f32)
         # ---- mixer -> backbone projection
         if cfg.use_patch_mixer and cfg.has_maps:
             self.lin_wgrad(dx, tp.xout_ln, "patch_mixer_map_xout.1", B * Tk, D, Dm)
@@ -919,8 +971,10 @@ class DiTEngine:
         has_maps = cfg.use_patch_mixer and cfg.has_maps
         dym_f32 = self.zeros(Mc, Dm) if has_maps else dy2_f32
         for bp, bt in zip(reversed(self.mixer), reversed(tp.mixer)):
-            self._block_bwd_scoped(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc, grp_m)
+            self._block_bwd_scoped(bp, bt, dx, tp.ym, dym_f32, B, T, Lc, gc, dgc, grp_m, kv_m)
             seg(bp.name)
+        if kv_m is not None:
+            self._dycond_grouped(kv_m, Mc, self.mixer[0].dim, 2 * self.mixer[0].xattn_hidden, dym_f32)
         # ---- map_xin / patch embedding
         if has_maps:
             self.lin_wgrad(dx, tp.xin_ln, "patch_mixer_map_xin.1", B * T, Dm, D)

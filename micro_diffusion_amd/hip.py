@@ -106,7 +106,7 @@ class GemmArgs(Structure):
         ("rows_per_sample", c_int64),
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
-        ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p),
+        ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p), ("list_segments", c_int32),
     ]
 
 
@@ -197,8 +197,8 @@ _sig("md_gemm_bf16", POINTER(GemmArgs), P)
 _sig("md_splitk_reduce", P, P, I64, I64, I64, I64, I32, I32, I32, P)
 _sig("md_ln_fwd", POINTER(LnArgs), P)
 _sig("md_ln_bwd", POINTER(LnArgs), POINTER(LnBwdArgs), P)
-_sig("md_qkln_fwd", P, I64, I64, I64, I64, P, F32, P)
-_sig("md_qkln_bwd", P, I64, I64, P, I64, I64, I64, I64, P, P)
+_sig("md_qkln_fwd", P, I64, I64, I64, I64, I32, I64, P, F32, P)
+_sig("md_qkln_bwd", P, I64, I64, P, I64, I64, I64, I64, I32, I64, I64, P, P)
 _sig("md_attn_fwd", POINTER(AttnArgs), P)
 _sig("md_attn_bwd", POINTER(AttnArgs), P)
 _sig("md_swiglu_fwd", P, I64, P, I64, I64, I64, P)
@@ -208,6 +208,7 @@ _sig("md_act_fwd", P, P, I64, I32, P)
 _sig("md_act_bwd", P, P, P, I64, I32, P)
 _sig("md_colsum", P, I32, I64, P, I64, I64, P)
 _sig("md_cast_f32_bf16", P, P, I64, P, P)
+_sig("md_cast_f32_bf16_clear", P, P, I64, P)
 _sig("md_cast_rows_bf16", P, I32, P, I64, I64, P, I64, P)
 _sig("md_mean_tokens", P, P, I64, I64, I64, P)
 _sig("md_mean_tokens_bwd", P, P, I64, I64, I64, P)
@@ -259,7 +260,7 @@ def stream_ptr():
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
-         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, chosen=None):
+         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
     def ptr(x):
         if x is None:
@@ -268,7 +269,7 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
-                 ptr(timeline), None, ptr(A_list), ptr(B_list))
+                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments)
     ch = ctypes.c_int32(-1)
     a.chosen_variant = ctypes.addressof(ch)
     rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())

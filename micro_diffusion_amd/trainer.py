@@ -91,15 +91,36 @@ class FusedAdamW:
         self.ema_live = False
         self.last_grad_scale = 1.0
 
+    def _launch(self, off: int, n: int, lr: float, max_norm: float, grad_scale: float, ss, g_bf16_ptr, shadow_ptr, zero_grad: int,
+                ema_mode: int) -> None:
+        """md_adamw_step on elements [off, off + n) of the flat buffers; the bf16 gradient / bf16 weight output may live elsewhere
+        (the packed per-rank buffers of the sharded exchange)."""
+        f = self.dit.flat_buffers()
+        L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
+        b1, b2 = self.betas
+        a = hip.AdamWArgs(f["p"].data_ptr() + 4 * off, f["g"].data_ptr() + 4 * off, self.m.data_ptr() + 4 * off,
+                          self.v.data_ptr() + 4 * off, shadow_ptr, ss, g_bf16_ptr,
+                          (self.ema.data_ptr() + 4 * off) if self.ema is not None else None, n, lr, b1, b2, self.eps,
+                          self.weight_decay, 1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale,
+                          self.ema_smoothing or 0.0, zero_grad, ema_mode)
+        hip.check(L.md_adamw_step(byref(a), st), "md_adamw_step")
+
+    def _begin_step(self, grad_scale: float) -> int:
+        self.step_count += 1
+        self.last_grad_scale = grad_scale
+        ema_mode = 0
+        if self.ema is not None and self.step_count > self.ema_start:
+            ema_mode = 2 if self.ema_live else 1          # first EMA batch: ema <- weights (the EMA model starts as a copy)
+            self.ema_live = True
+        return ema_mode
+
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0, g_bf16: Optional[torch.Tensor] = None,
              norm_partials: int = 0) -> None:
         """`g_bf16`: take the gradients from this bf16 flat buffer (data-parallel exchange buffer) instead of the fp32
         accumulators.  `norm_partials` > 0: that many per-bucket partial sums of squares are already in self.partials."""
         f = self.dit.flat_buffers()
         L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
-        self.step_count += 1
-        self.last_grad_scale = grad_scale
-        b1, b2 = self.betas
+        ema_mode = self._begin_step(grad_scale)
         ss = None
         if max_norm and max_norm > 0:
             if norm_partials <= 0:
@@ -108,16 +129,35 @@ class FusedAdamW:
                 norm_partials = hip.SUMSQ_PARTIALS
             hip.check(L.md_sumsq_finish(self.partials.data_ptr(), norm_partials, self.sumsq.data_ptr(), st), "md_sumsq_finish")
             ss = self.sumsq.data_ptr()
-        ema_mode = 0
-        if self.ema is not None and self.step_count > self.ema_start:
-            ema_mode = 2 if self.ema_live else 1          # first EMA batch: ema <- weights (the EMA model starts as a copy)
-            self.ema_live = True
-        a = hip.AdamWArgs(f["p"].data_ptr(), f["g"].data_ptr(), self.m.data_ptr(), self.v.data_ptr(), f["s"].data_ptr(), ss,
-                          g_bf16.data_ptr() if g_bf16 is not None else None, self.ema.data_ptr() if self.ema is not None else None,
-                          f["total"], self.lr if lr is None else lr, b1, b2, self.eps, self.weight_decay,
-                          1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale,
-                          self.ema_smoothing or 0.0, 1, ema_mode)
-        hip.check(L.md_adamw_step(byref(a), st), "md_adamw_step")
+        self._launch(0, f["total"], self.lr if lr is None else lr, max_norm, grad_scale, ss,
+                     g_bf16.data_ptr() if g_bf16 is not None else None, f["s"].data_ptr(), 1, ema_mode)
+        self.dit.mark_shadow_fresh()
+
+    def step_sharded(self, sync: "GradSync", lr: Optional[float] = None, max_norm: float = 0.0, grad_scale: float = 1.0,
+                     norm_slots: int = 0, chunk_of: Optional[int] = None) -> None:
+        """The rank's share of the step under GradSync(mode='sharded'): ||g||^2 from the ranks' chunk norms (one scalar
+        all-reduce), AdamW on this rank's chunk of every matrix-shaped bucket (gradient from the reduce-scattered bf16 buffer,
+        fresh bf16 weights into the packed send buffer) and on the whole "small" region (every rank), then the asynchronous
+        all-gather of the bf16 weights.  The fp32 accumulators were cleared by the staging cast.
+        `chunk_of` (measurement aid, single rank): pretend to be one of `chunk_of` ranks — update only the first 1 / chunk_of of
+        every bucket — to time the per-rank optimiser pass of an N-GPU run on one GPU; the model is NOT valid afterwards."""
+        f = self.dit.flat_buffers()
+        ema_mode = self._begin_step(grad_scale)
+        lr = self.lr if lr is None else lr
+        ss = None
+        if max_norm and max_norm > 0:
+            sync.finish_sharded_norm(norm_slots, self.sumsq)
+            ss = self.sumsq.data_ptr()
+        for key, lo, hi, chunk, olo in sync.plan:
+            n = chunk if chunk_of is None else (hi - lo) // chunk_of // 64 * 64
+            if n <= 0:
+                continue
+            self._launch(lo + sync.rank * chunk, n, lr, max_norm, grad_scale, ss, sync.gred.data_ptr() + 2 * olo,
+                         sync.ssend.data_ptr() + 2 * olo, 0, ema_mode)
+        if sync.small is not None:
+            lo, hi = sync.small
+            self._launch(lo, hi - lo, lr, max_norm, grad_scale, ss, sync.gbf.data_ptr() + 2 * lo, f["s"].data_ptr() + 2 * lo, 0, ema_mode)
+        sync.gather_shadows()
         self.dit.mark_shadow_fresh()
 
     def grad_norm(self) -> torch.Tensor:
@@ -126,18 +166,35 @@ class FusedAdamW:
         the optimiser kernel."""
         return self.sumsq.sqrt() * self.last_grad_scale
 
+    def _by_name(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        f = self.dit.flat_buffers()
+        return {name: flat[f["offs"][name]:f["offs"][name] + view.numel()].view(view.shape) for name, view in f["P"].items()}
+
     def state_dict(self):
-        sd = {"m": self.m, "v": self.v, "step": self.step_count}
+        """Moments (and EMA) keyed by parameter name, like torch.optim's per-parameter state: independent of the flat layout."""
+        sd = {"m": self._by_name(self.m), "v": self._by_name(self.v), "step": self.step_count, "format": "by_name"}
         if self.ema is not None:
-            sd["ema"], sd["ema_live"] = self.ema, self.ema_live
+            sd["ema"], sd["ema_live"] = self._by_name(self.ema), self.ema_live
         return sd
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+        def put(dst_flat, src):
+            if isinstance(src, dict):
+                views = self._by_name(dst_flat)
+                if set(views) != set(src):
+                    raise RuntimeError(f"optimizer state names differ from the model's: {sorted(set(views) ^ set(src))[:4]} ...")
+                for k, v in views.items():
+                    v.copy_(src[k])
+            else:                           # a flat tensor: only valid for the layout it was saved from
+                if src.numel() != dst_flat.numel():
+                    raise RuntimeError(f"flat optimizer state has {src.numel()} elements, the model's buffers have {dst_flat.numel()} "
+                                       "(saved under a different flat layout: re-save it keyed by name)")
+                dst_flat.copy_(src)
+        put(self.m, sd["m"])
+        put(self.v, sd["v"])
         self.step_count = int(sd["step"])
         if self.ema is not None and "ema" in sd:
-            self.ema.copy_(sd["ema"])
+            put(self.ema, sd["ema"])
             self.ema_live = bool(sd.get("ema_live", True))
         elif self.ema is not None and self.step_count > self.ema_start:
             # resuming past ema_start from a checkpoint that holds no EMA: the average would silently restart from the
@@ -193,112 +250,195 @@ class FusedAdamW:
         return FusedAdamW._EmaSwap(self)
 
 
+def shard_plan(buckets, world: int):
+    """Rank chunks of the data-parallel buckets.  `buckets` = [(key, lo, hi)] tiling the flat buffer (dit.bucket_ranges; every
+    boundary is a multiple of dit._BUCKET_ALIGN, so (hi - lo) / world is a whole number of 128-byte lines for world <= 16).
+    Returns [(key, lo, hi, chunk, olo)] for the matrix-shaped buckets in flat (= forward) order — rank r owns
+    [lo + r * chunk, lo + (r + 1) * chunk) of bucket i and keeps its reduced gradient / fresh bf16 weights at [olo, olo + chunk)
+    of a packed per-rank buffer — and the (lo, hi) of the "small" region every rank owns whole."""
+    plan, olo, small = [], 0, None
+    for key, lo, hi in buckets:
+        if key == "small":
+            small = (lo, hi)
+            continue
+        n = hi - lo
+        if n % world or (n // world) % 64:
+            raise ValueError(f"bucket {key} [{lo}, {hi}) does not split into {world} aligned chunks")
+        plan.append((key, lo, hi, n // world, olo))
+        olo += n // world
+    return plan, small, olo
+
+
 class GradSync:
-    """Overlapped data-parallel gradient averaging (the reference's FSDP gradient reduction, configs/*.yaml fsdp_config).
+    """Overlapped data-parallel gradient exchange (the reference's FSDP gradient reduction, configs/*.yaml fsdp_config:
+    SHARD_GRAD_OP = gradients and optimiser state sharded, weights whole).
 
-    As soon as the engine reports the backward of a segment (final layer, one DiT block, ...) as enqueued, that segment of
-    the flat gradient buffer is handed to RCCL (torch.distributed, backend "nccl" = RCCL over xGMI; async: the collective
-    runs on RCCL's own stream behind an event on the compute stream) while the remaining backward kernels keep the CUs busy.
-    Exchange formats:
-      "bf16"  the segment is cast into a bf16 staging buffer (one HIP kernel) and THAT is all-reduced: 2.33 GB instead of
-              4.66 GB per step for XL/2 (FSDP's default mixed precision reduces gradients in the low precision too, SURVEY.md
-              C.7); the optimiser kernel reads the reduced bf16 gradients and still zeroes the fp32 accumulators;
-      "fp32"  in-place all-reduce of the fp32 accumulators (gloo / parity runs).
-    The squared norm of every reduced segment is taken on a side stream right behind its collective (deterministic partial
-    sums, md_sumsq), so the clip coefficient needs no extra pass after the last bucket and is bit-identical on all ranks."""
+    As soon as the engine reports the backward of a segment (final layer, one DiT block, ...) as enqueued, that bucket of the
+    flat gradient buffer is handed to RCCL (torch.distributed, backend "nccl" = RCCL over xGMI; async: the collective runs on
+    RCCL's own stream behind an event on the compute stream) while the remaining backward kernels keep the CUs busy.
 
-    def __init__(self, dit, process_group=None, exchange: str = "auto", single_rank_exchange: bool = False):
-        """`single_rank_exchange`: run the whole exchange path (staging cast, asynchronous collective, side-stream norm) also on
-        a process group of ONE rank, where the all-reduce is the identity — the only way to drive the RCCL code path on a box
+    mode "sharded" (default for N > 1 with the bf16 exchange): ZeRO-1 in the reference's sense —
+      * a bucket is staged as bf16 (md_cast_f32_bf16_clear: the fp32 accumulators come back zeroed) and REDUCE-SCATTERED: rank r
+        receives the sum of chunk r only (half the bytes an all-reduce moves per rank);
+      * each rank takes the squared norm of ITS chunks on a side stream; one scalar all-reduce completes ||g||^2 (identical on
+        all ranks);
+      * FusedAdamW.step_sharded updates the rank's chunks of weights / moments (1 / N of the 34 B per parameter pass) and writes
+        their fresh bf16 values into a packed send buffer;
+      * the bf16 shadow weights are ALL-GATHERED bucket by bucket in forward order, asynchronously; the engine waits for a
+        bucket right before the first kernel that reads it (DiTEngine.before_segment), so the gather hides under the next forward;
+      * one-dimensional tensors (the "small" region: the engine reads them from the fp32 masters) are all-reduced as one bucket
+        and updated by every rank.
+      The fp32 masters / moments of foreign chunks go stale: Trainer.consolidate() all-gathers them before a checkpoint or an
+      evaluation on EMA weights.
+    mode "allreduce": every bucket all-reduced, every rank runs the whole optimiser pass (round 2's exchange; also the fp32 /
+      gloo parity path).  Exchange formats: "bf16" (2.33 GB per step for XL/2; FSDP's default mixed precision reduces in the low
+      precision too, SURVEY.md C.7 -- measured effect at 8 ranks: tests/test_abi_and_dp_cpu.py) or "fp32" in place.
+    The squared norm of every reduced bucket is taken on a side stream right behind its collective (deterministic partial sums,
+    md_sumsq), so the clip coefficient needs no extra pass after the last bucket and is bit-identical on all ranks."""
+
+    def __init__(self, dit, process_group=None, exchange: str = "auto", single_rank_exchange: bool = False, mode: str = "auto"):
+        """`single_rank_exchange`: run the whole exchange path (staging cast, asynchronous collectives, side-stream norm) also on
+        a process group of ONE rank, where every collective is the identity — the only way to drive the RCCL code path on a box
         with a single GPU (tests/test_dp_gpu.py); never set in production."""
         self.dit = dit
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.enabled = self.world > 1 or (single_rank_exchange and dist.is_initialized())
         if exchange == "auto":
             exchange = "bf16" if (self.enabled and dist.get_backend(process_group) == "nccl") else "fp32"
         assert exchange in ("bf16", "fp32")
-        self.exchange = exchange
+        if mode == "auto":
+            mode = "sharded" if (self.enabled and exchange == "bf16") else "allreduce"
+        assert mode in ("sharded", "allreduce")
+        if mode == "sharded" and exchange != "bf16":
+            raise ValueError("the sharded exchange stages gradients as bf16 (exchange='bf16')")
+        self.exchange, self.mode = exchange, mode
         f = dit.flat_buffers()
-        # segment prefix -> [start, end) in the flat buffer (table order is contiguous per module)
-        import numpy as np
-        self.ranges: Dict[str, List[int]] = {}
-        for spec in dit._table:
-            if spec.buffer:
-                continue
-            top = spec.name.split(".")
-            key = ".".join(top[:2]) if top[0] in ("blocks", "patch_mixer") else ("final_layer" if top[0] == "final_layer" else "rest")
-            o = f["offs"][spec.name]
-            n = ((int(np.prod(spec.shape)) + 63) // 64) * 64
-            r = self.ranges.setdefault(key, [o, o + n])
-            r[0], r[1] = min(r[0], o), max(r[1], o + n)
+        buckets = f.get("buckets")
+        if buckets is None:                                   # a bare table (CPU tests): derive the ranges here
+            from .dit import bucket_ranges
+            buckets = bucket_ranges(dit._table, f["offs"], f["total"])
+        self.bucket_list = list(buckets)
+        # segment name reported by the engine -> its ranges ("rest" also flushes "small": both complete with the last segment)
+        self.ranges: Dict[str, List[tuple]] = {}
+        for key, lo, hi in self.bucket_list:
+            self.ranges.setdefault(key, []).append((lo, hi))
         self.pending = []
         self.active = False
         self.buckets = 0                 # buckets handed over in the current step (= partial-sum slots in use)
         self.last_buckets = 0            # ... in the last finished step (bench.py dp block)
-        self.step_bytes = self.last_bytes = 0   # bytes handed to the collective in the current / last step
+        self.step_bytes = self.last_bytes = 0   # bytes handed to the collectives in the current / last step
         self.norm_partials: Optional[torch.Tensor] = None     # set by the Trainer: FusedAdamW.partials
-        self.gbf = torch.empty(f["total"], device=f["g"].device, dtype=torch.bfloat16) if (exchange == "bf16" and self.enabled) else None
-        self.side = torch.cuda.Stream(device=f["g"].device) if (self.enabled and f["g"].is_cuda) else None
-        self.host_bounce = self.enabled and f["g"].is_cuda and dist.get_backend(process_group) != "nccl"
+        on_gpu = f["g"].is_cuda
+        dev = f["g"].device
+        self.gbf = torch.zeros(f["total"], device=dev, dtype=torch.bfloat16) if (exchange == "bf16" and self.enabled) else None
+        self.side = torch.cuda.Stream(device=dev) if (self.enabled and on_gpu) else None
+        self.host_bounce = self.enabled and on_gpu and dist.get_backend(process_group) != "nccl"
+        self.plan = self.small = None
+        self.gather_work: Dict[str, list] = {}
+        if mode == "sharded":
+            self.plan, self.small, own = shard_plan(self.bucket_list, self.world)
+            self.by_range = {(lo, hi): (chunk, olo) for _, lo, hi, chunk, olo in self.plan}
+            self.gred = torch.zeros(max(own, 8), device=dev, dtype=torch.bfloat16)     # reduced gradient of this rank's chunks
+            self.ssend = torch.zeros(max(own, 8), device=dev, dtype=torch.bfloat16)    # fresh bf16 weights of this rank's chunks
+            # [small-region partial sums (SUMSQ_PARTIALS floats) | sum over the ranks' chunk norms (1 float)] -> md_sumsq_finish
+            self.fin = torch.zeros(hip.SUMSQ_PARTIALS + 8, device=dev)
 
     def describe(self) -> str:
         if not self.enabled:
             return "none (single rank)"
-        return f"{self.exchange} all-reduce per backward segment ({len(self.ranges) + 2} buckets), overlapped with backward"
+        n = len(self.bucket_list)
+        if self.mode == "sharded":
+            return (f"bf16 reduce-scatter per backward segment ({n} buckets, 1-D tensors all-reduced), sharded AdamW, bf16 weights "
+                    "all-gathered under the next forward")
+        return f"{self.exchange} all-reduce per backward segment ({n} buckets), overlapped with backward"
+
+    # ------------------------------------------------------------------ collectives (RCCL, or a host bounce under gloo)
+    def _all_reduce(self, buf):
+        if self.host_bounce:
+            h = buf.float().cpu() if buf.dtype == torch.bfloat16 else buf.cpu()
+            dist.all_reduce(h, group=self.pg)
+            buf.copy_(h.to(buf.dtype))
+            return None
+        return dist.all_reduce(buf, group=self.pg, async_op=True)
+
+    def _reduce_scatter(self, out, buf):
+        if self.host_bounce:               # gloo has no reduce-scatter: all-reduce on the host, keep this rank's chunk
+            h = buf.float().cpu()
+            dist.all_reduce(h, group=self.pg)
+            c = out.numel()
+            out.copy_(h[self.rank * c:(self.rank + 1) * c].to(out.dtype))
+            return None
+        return dist.reduce_scatter_tensor(out, buf, group=self.pg, async_op=True)
+
+    def _all_gather(self, out, mine):
+        if self.host_bounce:
+            h = mine.float().cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.pg)
+            out.copy_(torch.cat(parts).to(out.dtype))
+            return None
+        return dist.all_gather_into_tensor(out, mine, group=self.pg, async_op=True)
+
+    def _norm_after(self, work, buf, is_bf16, slot_ptr):
+        """||buf||^2 partial sums on the side stream, right behind the collective that produced buf."""
+        if self.side is None:
+            return
+        if work is None:
+            self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            if work is not None:
+                work.wait()              # stream-side dependency under NCCL; the norm overlaps the remaining backward
+            hip.check(hip.lib().md_sumsq(buf.data_ptr(), 1 if is_bf16 else 0, buf.numel(), slot_ptr, self.side.cuda_stream), "md_sumsq")
 
     def _exchange(self, lo: int, hi: int) -> None:
         f = self.dit.flat_buffers()
         g = f["g"][lo:hi]
+        st = torch.cuda.current_stream().cuda_stream if g.is_cuda else None
+        sharded = self.mode == "sharded"
+        small = sharded and self.small is not None and (lo, hi) == tuple(self.small)
         if self.exchange == "bf16":
             buf = self.gbf[lo:hi]
-            hip.check(hip.lib().md_cast_f32_bf16(g.data_ptr(), buf.data_ptr(), hi - lo, None, torch.cuda.current_stream().cuda_stream), "cast")
+            if sharded:                   # the fp32 accumulators come back cleared (no later pass visits all of them)
+                hip.check(hip.lib().md_cast_f32_bf16_clear(g.data_ptr(), buf.data_ptr(), hi - lo, st), "cast_clear")
+            else:
+                hip.check(hip.lib().md_cast_f32_bf16(g.data_ptr(), buf.data_ptr(), hi - lo, None, st), "cast")
         else:
             buf = g
-        if self.host_bounce:
-            # gloo (functional runs of several ranks on one GPU, CPU tests): reduce through host memory, synchronously
-            h = buf.float().cpu() if buf.dtype == torch.bfloat16 else buf.cpu()
-            dist.all_reduce(h, group=self.pg)
-            buf.copy_(h.to(buf.dtype))
-            work = None
-        else:
-            work = dist.all_reduce(buf, group=self.pg, async_op=True)
-        slot = self.buckets
-        self.buckets += 1
         self.step_bytes += buf.numel() * buf.element_size()
-        if self.norm_partials is not None and self.side is not None and slot < FusedAdamW.MAX_BUCKETS:
-            if work is None:
-                self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                if work is not None:
-                    work.wait()          # stream-side dependency under NCCL; the norm overlaps the remaining backward
-                hip.check(hip.lib().md_sumsq(buf.data_ptr(), 1 if self.exchange == "bf16" else 0, hi - lo,
-                                             self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS, self.side.cuda_stream), "md_sumsq")
+        if sharded and not small:
+            chunk, olo = self.by_range[(lo, hi)]
+            red = self.gred[olo:olo + chunk]
+            work = self._reduce_scatter(red, buf)
+            slot = self.buckets
+            self.buckets += 1
+            if self.norm_partials is not None and slot < FusedAdamW.MAX_BUCKETS:
+                self._norm_after(work, red, True, self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS)
+        elif small:
+            work = self._all_reduce(buf)
+            self._norm_after(work, buf, True, self.fin.data_ptr())        # identical on every rank: added once, after the scalar all-reduce
+        else:
+            work = self._all_reduce(buf)
+            slot = self.buckets
+            self.buckets += 1
+            if self.norm_partials is not None and slot < FusedAdamW.MAX_BUCKETS:
+                self._norm_after(work, buf, self.exchange == "bf16", self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS)
         if work is not None:
             self.pending.append(work)
 
     def on_segment(self, name: str) -> None:
         if not self.active or not self.enabled:
             return
-        for lo, hi in (self._rest_ranges() if name == "rest" else [tuple(self.ranges[name])]):
+        for lo, hi in self.ranges.get(name, []):
             self._exchange(lo, hi)
-
-    def _rest_ranges(self):
-        """'rest' = everything that is not a DiT block or the final layer; not contiguous (front end precedes the
-        mixer, the mixer maps sit between mixer and backbone): reduce the gaps between the block ranges."""
-        total = self.dit.flat_buffers()["total"]
-        taken = sorted(v for k, v in self.ranges.items() if k != "rest")
-        out, cur = [], 0
-        for lo, hi in taken:
-            if lo > cur:
-                out.append((cur, lo))
-            cur = max(cur, hi)
-        if cur < total:
-            out.append((cur, total))
-        return out
+        if name == "rest":                # the last segment of a backward: the one-dimensional tensors are complete too
+            for lo, hi in self.ranges.get("small", []):
+                self._exchange(lo, hi)
 
     def finish(self) -> int:
-        """Wait for every bucket; returns the number of norm partial-sum slots filled (0 = the optimiser takes the norm itself)."""
+        """Wait for every bucket; returns the number of norm partial-sum slots filled (0 = the optimiser takes the norm itself;
+        sharded mode: the finished ||g||^2 is written to `sumsq_out` by finish_sharded_norm instead)."""
         for w in self.pending:
             w.wait()
         self.pending = []
@@ -309,17 +449,59 @@ class GradSync:
         self.buckets = self.step_bytes = 0
         return n
 
+    def finish_sharded_norm(self, slots: int, sumsq_out: torch.Tensor) -> None:
+        """||g||^2 of the rank-summed gradient from the ranks' chunk partial sums: local finish -> scalar all-reduce -> + the small
+        region's partial sums (every rank holds the same ones) -> sumsq_out.  Fixed summation order everywhere: identical bits on
+        all ranks."""
+        L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
+        P = hip.SUMSQ_PARTIALS
+        tot = self.fin[P:P + 1]
+        hip.check(L.md_sumsq_finish(self.norm_partials.data_ptr(), slots * P, tot.data_ptr(), st), "md_sumsq_finish")
+        w = self._all_reduce(tot)
+        if w is not None:
+            w.wait()
+        hip.check(L.md_sumsq_finish(self.fin.data_ptr(), P + 1, sumsq_out.data_ptr(), st), "md_sumsq_finish")
+
+    def gather_shadows(self) -> None:
+        """All-gather the fresh bf16 weights bucket by bucket in forward order (asynchronous); wait_gather(key) is the engine's
+        hook in front of the first kernel that reads a bucket."""
+        s = self.dit.flat_buffers()["s"]
+        for key, lo, hi, chunk, olo in self.plan:
+            w = self._all_gather(s[lo:hi], self.ssend[olo:olo + chunk])
+            self.step_bytes += (hi - lo) * 2
+            if w is not None:
+                self.gather_work.setdefault(key, []).append(w)
+
+    def wait_gather(self, key: Optional[str] = None) -> None:
+        if not self.gather_work:
+            return
+        keys = [key] if key is not None else list(self.gather_work)
+        for k in keys:
+            for w in self.gather_work.pop(k, []):
+                w.wait()
+
 
 class Trainer:
     def __init__(self, model, optimizer: FusedAdamW, schedule: Optional[LRSchedule] = None, clip_norm: float = 0.0,
                  microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None,
-                 exchange: str = "auto", single_rank_exchange: bool = False):
+                 exchange: str = "auto", single_rank_exchange: bool = False, dp_mode: str = "auto"):
+        """dp_mode: "sharded" (reduce-scatter + sharded AdamW + all-gather of the bf16 weights, the reference's SHARD_GRAD_OP;
+        default for N > 1 over RCCL) or "allreduce" (every rank runs the whole optimiser pass); "auto" also honours the
+        MD_DP_MODE environment variable."""
+        import os
         self.model, self.opt, self.schedule, self.clip_norm = model, optimizer, schedule, clip_norm
         self.microbatch_size = microbatch_size
-        self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange)
+        if dp_mode == "auto" and os.environ.get("MD_DP_MODE"):
+            dp_mode = os.environ["MD_DP_MODE"]
+        model.dit._ensure_flat()
+        self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange, mode=dp_mode)
         self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
+        self.sharded = self.sync.enabled and self.sync.mode == "sharded"
+        self.stale_foreign_chunks = False    # sharded: fp32 masters / moments of the other ranks' chunks are out of date
+        self.shard_chunk_of = None           # measurement aid, see FusedAdamW.step_sharded
         model.dit._on_segment = self.sync.on_segment
+        model.dit.engine.before_segment = self.sync.wait_gather if self.sharded else None
         # the Trainer runs forward -> backward strictly in turn: activations may live in the engine's fixed-address arenas
         model.dit._ensure_flat()
         model.dit.engine.use_arena = True
@@ -328,6 +510,7 @@ class Trainer:
         self._win: List[tuple] = []
         self.measure_comm = False          # bench.py: event pairs around GradSync.finish() (exposed exchange time)
         self._comm_events: List[tuple] = []
+        self._opt_events: List[tuple] = []
 
     def train_step(self, batch: dict) -> torch.Tensor:
         """One optimisation step on this rank's share of the global batch.  Returns the rank-mean loss (device scalar).
@@ -354,8 +537,19 @@ class Trainer:
             e1.record()                                  # behind the waits on the collectives / side-stream norms
             self._comm_events.append((e0, e1))
         fac = self.schedule.factor(self.batches_seen) if self.schedule is not None else 1.0
-        self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
-                      g_bf16=self.sync.gbf, norm_partials=slots * hip.SUMSQ_PARTIALS)
+        if self.measure_comm:
+            o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            o0.record()
+        if self.sharded:
+            self.opt.step_sharded(self.sync, lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
+                                  norm_slots=slots, chunk_of=self.shard_chunk_of)
+            self.stale_foreign_chunks = self.world > 1
+        else:
+            self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
+                          g_bf16=self.sync.gbf, norm_partials=slots * hip.SUMSQ_PARTIALS)
+        if self.measure_comm:
+            o1.record()                                  # norm finish + AdamW (+ the launch of the weight all-gathers)
+            self._opt_events.append((o0, o1))
         self.batches_seen += 1
         return total.reshape(())
 
@@ -366,6 +560,32 @@ class Trainer:
             return None
         torch.cuda.synchronize()
         ev = self._comm_events[-last:] if last > 0 else self._comm_events
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    def consolidate(self) -> None:
+        """Sharded optimiser only: all-gather the fp32 masters, both moments and the EMA so that every rank holds the whole,
+        current state (checkpoints, evaluation on EMA weights, state_dict()).  A collective: every rank must call it.  Not on the
+        step path (3 x 4.66 GB for XL/2, at checkpoint / evaluation intervals)."""
+        if not self.sharded or not self.stale_foreign_chunks:
+            return
+        s = self.sync
+        s.wait_gather()
+        f = self.model.dit.flat_buffers()
+        bufs = [f["p"], self.opt.m, self.opt.v] + ([self.opt.ema] if self.opt.ema is not None else [])
+        for t in bufs:
+            for key, lo, hi, chunk, olo in s.plan:
+                mine = t[lo + s.rank * chunk: lo + (s.rank + 1) * chunk].clone()
+                w = s._all_gather(t[lo:hi], mine)
+                if w is not None:
+                    w.wait()
+        self.stale_foreign_chunks = False
+
+    def optimizer_ms(self, last: int = 0) -> Optional[float]:
+        """Mean compute-stream time per step of the gradient-norm finish + AdamW pass (needs measure_comm; synchronises)."""
+        if not self._opt_events:
+            return None
+        torch.cuda.synchronize()
+        ev = self._opt_events[-last:] if last > 0 else self._opt_events
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def sync_replicas(self) -> None:
@@ -386,11 +606,13 @@ class Trainer:
         self.model.dit.refresh_shadow(force=True)
 
     def replicas_in_sync(self) -> bool:
-        """True when the fp32 master weights of all ranks have the same checksum (sum and sum of squares in fp64); cheap enough
-        to run every few hundred batches."""
+        """True when the weights of all ranks have the same checksum (sum and sum of squares in fp64, taken over the bf16 shadow
+        every rank computes with: under the sharded optimiser the fp32 masters of foreign chunks are deliberately stale); cheap
+        enough to run every few hundred batches."""
         if self.world <= 1:
             return True
-        p = self.model.dit.flat_buffers()["p"].double()
+        self.sync.wait_gather()
+        p = self.model.dit.flat_buffers()["s"].double()
         mine = torch.stack([p.sum(), (p * p).sum()])
         lo, hi = mine.clone(), mine.clone()
         if self.sync.host_bounce:

@@ -348,6 +348,8 @@ def edm_loss(sd: SD, cfg: RefConfig, x: Tensor, y: Tensor, rnd_normal: Tensor, e
     c_noise = sigma.log() / 4
     Fx, mask = dit_forward(sd, cfg, c_in * xn, c_noise.flatten(), y, mask_ratio, mask_noise, taps=taps)
     D = c_skip * xn + c_out * Fx
+    if taps is not None:
+        taps["F"] = Fx.detach()
     loss = weight * (D - x) ** 2
     if mask_ratio > 0:
         loss = F.avg_pool2d(loss.mean(dim=1), cfg.patch_size).flatten(1)

@@ -38,6 +38,8 @@ def main():
             for k, val in kv.items():
                 base.setdefault(k, getattr(eng, k))
                 setattr(eng, k, type(getattr(eng, k))(int(val)))
+            for ar in (eng._tape_arena, eng._scratch_arena):     # the launch sequence may change with the options: re-measure
+                ar.peaks.clear()
             e, loss = st.timed(a.steps, 1, 1)
             res.setdefault(name, []).append(2048 * a.steps / e)
             print(f"{name:24s} round {rnd}: {2048 * a.steps / e:8.1f} img/s  loss {loss:.5f}", flush=True)

@@ -52,7 +52,7 @@ for name, rows, C, rps in (("backbone", args.mb * 64, 1024, 64), ("mixer", args.
     qkv = (torch.randn(rows, 3 * C, device=dev)).to(torch.bfloat16)
     dqkv = torch.randn(rows, 3 * C, device=dev).to(torch.bfloat16)
     rq = torch.empty(rows, device=dev)
-    timed(lambda: hip.check(L.md_qkln_fwd(qkv.data_ptr(), rows, 3 * C, 0, C, rq.data_ptr(), 1e-6, st), "q"), rows * C * 4,
+    timed(lambda: hip.check(L.md_qkln_fwd(qkv.data_ptr(), rows, 3 * C, 0, C, 1, 0, rq.data_ptr(), 1e-6, st), "q"), rows * C * 4,
           f"{name} qkln_fwd [{rows} x {C} of {3 * C}]")
-    timed(lambda: hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * C, 0, qkv.data_ptr(), 3 * C, 0, rows, C, rq.data_ptr(), st), "qb"),
+    timed(lambda: hip.check(L.md_qkln_bwd(dqkv.data_ptr(), 3 * C, 0, qkv.data_ptr(), 3 * C, 0, rows, C, 1, 0, 0, rq.data_ptr(), st), "qb"),
           rows * C * 6, f"{name} qkln_bwd [{rows} x {C} of {3 * C}]")

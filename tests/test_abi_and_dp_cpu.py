@@ -191,3 +191,41 @@ def test_bf16_gradient_exchange_error_at_8_ranks():
     assert res["fp32"] < 1e-6
     assert res["bf16_in_f32_acc"] < 3e-3 and res["bf16_hop_rounded"] < 6e-3, res
     assert res["norm_bf16_in_f32_acc"] < 2e-4 and res["norm_bf16_hop_rounded"] < 5e-4, res
+
+
+def test_shard_plan_partitions_every_bucket():
+    """trainer.shard_plan (host logic of the sharded optimiser step, the reference's SHARD_GRAD_OP): for world sizes 1..16 the
+    rank chunks of every matrix-shaped bucket of the XL/2 layout tile the bucket exactly once, are 128-byte aligned in bf16,
+    the packed per-rank offsets are contiguous, every one-dimensional tensor lies in the "small" tail region and nowhere else,
+    and [w1; w2] of a SwiGLU stay adjacent (the fused FFN GEMMs rely on it)."""
+    import numpy as np
+    from micro_diffusion_amd import dit as mdit
+    from micro_diffusion_amd.arch import bucket_key
+    from micro_diffusion_amd.trainer import shard_plan
+    m = mdit.MicroDiT_XL_2()
+    offs, total = mdit.flat_layout(m._table)
+    buckets = mdit.bucket_ranges(m._table, offs, total)
+    assert buckets[0][1] == 0 and buckets[-1][2] == total and all(a[2] == b[1] for a, b in zip(buckets, buckets[1:]))
+    assert [k for k, _, _ in buckets].count("small") == 1 and buckets[-1][0] == "small"
+    for spec in m._table:
+        if spec.buffer:
+            continue
+        key = bucket_key(spec.name, len(spec.shape))
+        o, n = offs[spec.name], int(np.prod(spec.shape))
+        assert o % 64 == 0
+        home = [b for b in buckets if b[1] <= o and o + n <= b[2]]
+        assert len(home) == 1 and home[0][0] == key, (spec.name, key, home)
+        assert (len(spec.shape) <= 1) == (key == "small")
+    w1 = next(s for s in m._table if s.name == "blocks.4.mlp.w1.weight")
+    assert offs["blocks.4.mlp.w2.weight"] == offs["blocks.4.mlp.w1.weight"] + int(np.prod(w1.shape))
+    for world in (1, 2, 4, 8, 16):
+        plan, small, own = shard_plan(buckets, world)
+        assert small == (buckets[-1][1], buckets[-1][2])
+        covered, nxt = 0, 0
+        for key, lo, hi, chunk, olo in plan:
+            assert chunk * world == hi - lo and chunk % 64 == 0 and olo == nxt
+            nxt += chunk
+            covered += hi - lo
+        assert nxt == own and covered + (small[1] - small[0]) == total
+    with pytest.raises(ValueError):
+        shard_plan([("rest", 0, 1024 * 3)], 7)

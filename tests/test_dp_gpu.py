@@ -28,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(world_batch_slice, exchange, microbatch):
+def _build(world_batch_slice, exchange, microbatch, dp_mode="allreduce"):
     from oracle import microdit_ref as orc
     from micro_diffusion_amd import dit as mdit
     from micro_diffusion_amd.model import LatentDiffusion, _FrozenStub
@@ -49,36 +49,49 @@ def _build(world_batch_slice, exchange, microbatch):
         return rnd[a:a + B].cuda(), epsn[a:a + B].cuda(), mnoise[a:a + B].cuda()
     model._noise_fn = noise_fn
     opt = FusedAdamW(model.dit, lr=2.4e-4)
-    tr = Trainer(model, opt, LRSchedule("constant", alpha=1.0), clip_norm=0.25, microbatch_size=microbatch, exchange=exchange)
+    tr = Trainer(model, opt, LRSchedule("constant", alpha=1.0), clip_norm=0.25, microbatch_size=microbatch, exchange=exchange,
+                 dp_mode=dp_mode)
     part = {k: v[lo:hi].cuda() for k, v in batch.items()}
     return model, opt, tr, part
 
 
-def _rank_main(rank, world, port, exchange, out_path):
+def _rank_main(rank, world, port, exchange, out_path, dp_mode="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         per = BATCH // world
-        model, opt, tr, part = _build((rank * per, (rank + 1) * per), exchange, per)
-        assert tr.world == world and tr.sync.exchange == exchange
+        model, opt, tr, part = _build((rank * per, (rank + 1) * per), exchange, per, dp_mode)
+        assert tr.world == world and tr.sync.exchange == exchange and tr.sync.mode == dp_mode
         loss = tr.train_step(part)
         torch.cuda.synchronize()
         flat = model.dit.flat_buffers()
+        shadow_ok = True
+        if dp_mode == "sharded":
+            # the bf16 weights every rank computes with are whole right after the step (all-gathered); the fp32 masters of the
+            # other rank's chunks are stale until consolidate()
+            tr.sync.wait_gather()
+            mine_s = flat["s"].float().cpu()
+            gs = [torch.empty_like(mine_s) for _ in range(world)]
+            dist.all_gather(gs, mine_s)
+            shadow_ok = all(torch.equal(gs[0], g) for g in gs)
+            assert tr.stale_foreign_chunks
+            tr.consolidate()
+            shadow_ok = shadow_ok and torch.equal(flat["s"], flat["p"].to(torch.bfloat16)) and float(flat["g"].abs().max()) == 0.0
         # every rank must hold identical weights after the step (no broadcast ever happens)
         mine = flat["p"].detach().cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         same = all(torch.equal(gathered[0], g) for g in gathered)
         if rank == 0:
-            torch.save({"p": mine, "gnorm": float(opt.grad_norm().item()), "loss": float(loss), "ranks_identical": same,
-                        "buckets": len(tr.sync.ranges)}, out_path)
+            torch.save({"p": mine, "gnorm": float(opt.grad_norm().item()), "loss": float(loss), "ranks_identical": same and shadow_ok,
+                        "buckets": len(tr.sync.bucket_list)}, out_path)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["fp32", "bf16"])
-def test_two_ranks_match_one_rank(hip, exchange):
+@pytest.mark.parametrize("exchange,dp_mode", [("fp32", "allreduce"), ("bf16", "allreduce"), ("bf16", "sharded")])
+def test_two_ranks_match_one_rank(hip, exchange, dp_mode):
     # ---- one rank, whole batch, two microbatches
     model, opt, tr, part = _build((0, BATCH), "fp32", BATCH // 2)
     tr.train_step(part)
@@ -92,14 +105,12 @@ def test_two_ranks_match_one_rank(hip, exchange):
         out = os.path.join(td, "rank0.pt")
         ctx = mp.get_context("spawn")
         port = _free_port()
-        procs = [ctx.Process(target=_rank_main, args=(r, 2, port, exchange, out)) for r in range(2)]
+        procs = [ctx.Process(target=_rank_main, args=(r, 2, port, exchange, out, dp_mode)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
             p.join(600)
         codes = [p.exitcode for p in procs]
-        if exchange == "bf16" and any(codes) and not os.path.exists(out):
-            pytest.skip(f"this gloo build cannot all-reduce bf16 tensors (exit codes {codes}); the bf16 exchange runs over RCCL only")
         assert codes == [0, 0], f"rank processes failed: {codes}"
         r = torch.load(out)
     assert r["ranks_identical"], "replicas diverged within one step"
@@ -110,7 +121,7 @@ def test_two_ranks_match_one_rank(hip, exchange):
     assert bad <= tol_frac, f"{bad:.2e} of the parameters differ by more than 1e-5 after one step"
 
 
-def _rccl_single_rank_main(port, exchange, out_path):
+def _rccl_single_rank_main(port, exchange, out_path, dp_mode="allreduce"):
     """One rank, backend "nccl" (= RCCL): every collective is the identity, but the calls are the production ones —
     asynchronous all-reduce on RCCL's stream behind an event on the compute stream, `work.wait()` as a stream dependency of
     the side stream that takes the bucket norms, the bf16 staging buffer feeding the optimiser kernel."""
@@ -120,8 +131,9 @@ def _rccl_single_rank_main(port, exchange, out_path):
     try:
         from micro_diffusion_amd.trainer import Trainer
         model, opt, tr, part = _build((0, BATCH), exchange, BATCH // 2)
-        tr = Trainer(model, opt, tr.schedule, clip_norm=0.25, microbatch_size=BATCH // 2, exchange=exchange, single_rank_exchange=True)
-        assert tr.sync.enabled and not tr.sync.host_bounce and tr.sync.exchange == exchange
+        tr = Trainer(model, opt, tr.schedule, clip_norm=0.25, microbatch_size=BATCH // 2, exchange=exchange, single_rank_exchange=True,
+                     dp_mode=dp_mode)
+        assert tr.sync.enabled and not tr.sync.host_bounce and tr.sync.exchange == exchange and tr.sync.mode == dp_mode
         seen = []
         inner = tr.sync._exchange
         tr.sync._exchange = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))[1]
@@ -130,15 +142,25 @@ def _rccl_single_rank_main(port, exchange, out_path):
         torch.cuda.synchronize()
         total = model.dit.flat_buffers()["total"]
         covered = sum(hi - lo for lo, hi in seen)
-        torch.save({"p": model.dit.flat_buffers()["p"].detach().cpu(), "gnorm": float(opt.grad_norm().item()), "loss": float(loss),
-                    "covered": covered, "total": total, "buckets": len(seen),
-                    "g_zeroed": bool((model.dit.flat_buffers()["g"] == 0).all().item())}, out_path)
+        res = {"p": model.dit.flat_buffers()["p"].detach().cpu(), "gnorm": float(opt.grad_norm().item()), "loss": float(loss),
+               "covered": covered, "total": total, "buckets": len(seen),
+               "g_zeroed": bool((model.dit.flat_buffers()["g"] == 0).all().item())}
+        if dp_mode == "sharded":
+            assert tr.sync.gather_work, "the bf16 weights are all-gathered asynchronously; the next forward waits per bucket"
+            f = model.dit.flat_buffers()
+            tr.sync.wait_gather()
+            torch.cuda.synchronize()
+            assert torch.equal(f["s"], f["p"].to(torch.bfloat16)), "gathered bf16 weights != round(fp32 masters)"
+            loss2 = tr.train_step(part)          # a second step: the forward waits on the gathers bucket by bucket
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss2).item()
+        torch.save(res, out_path)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["bf16", "fp32"])
-def test_rccl_exchange_path_on_one_rank(hip, exchange):
+@pytest.mark.parametrize("exchange,dp_mode", [("bf16", "allreduce"), ("fp32", "allreduce"), ("bf16", "sharded")])
+def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode):
     """The RCCL transport itself needs N GPUs, which a 1-GPU box does not have; the code AROUND it (everything GradSync does
     under backend "nccl" that the gloo test above replaces by a host bounce) runs here on a one-rank communicator and must
     reproduce the step without any exchange."""
@@ -152,7 +174,7 @@ def test_rccl_exchange_path_on_one_rank(hip, exchange):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "r.pt")
         ctx = mp.get_context("spawn")
-        proc = ctx.Process(target=_rccl_single_rank_main, args=(_free_port(), exchange, out))
+        proc = ctx.Process(target=_rccl_single_rank_main, args=(_free_port(), exchange, out, dp_mode))
         proc.start()
         proc.join(600)
         assert proc.exitcode == 0, f"RCCL single-rank process failed: {proc.exitcode}"

@@ -158,17 +158,23 @@ def _xl2_oracle(tag):
     return _XL2[tag]
 
 
-def _block_drift(tape, taps, cfg):
-    """rel-RMS of the residual stream after every block (product tape, bf16) against the oracle's (fp32): localises where a
-    loss difference is made.  tape.mixer[i].x / tape.blocks[i].x are the block INPUTS; the last backbone output is tape.xlast."""
+def _gain(a, b):
+    """Least-squares scale of a onto b: <a, b> / <b, b> (1 = no systematic shrink / growth of the product's activations)."""
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a * b).sum() / (b * b).sum())
+
+
+def _block_drift(tape, taps, cfg, fn=_rel_rms):
+    """rel-RMS (or gain) of the residual stream after every block (product tape, bf16) against the oracle's (fp32): localises
+    where a loss difference is made.  tape.mixer[i].x / tape.blocks[i].x are the block INPUTS; the last backbone output is tape.xlast."""
     mixer_specs, block_specs = orc.block_specs(cfg)
     out = {}
     outs_m = [t.x for t in tape.mixer[1:]]
     for spec, x in zip(mixer_specs[:-1], outs_m):
-        out[spec.prefix] = _rel_rms(x.float().cpu().view(-1), taps["out::" + spec.prefix].reshape(-1))
+        out[spec.prefix] = fn(x.float().cpu().view(-1), taps["out::" + spec.prefix].reshape(-1))
     outs_b = [t.x for t in tape.blocks[1:]] + [tape.xlast]
     for spec, x in zip(block_specs, outs_b):
-        out[spec.prefix] = _rel_rms(x.float().cpu().view(-1), taps["out::" + spec.prefix].reshape(-1))
+        out[spec.prefix] = fn(x.float().cpu().view(-1), taps["out::" + spec.prefix].reshape(-1))
     return out
 
 
@@ -211,6 +217,10 @@ def test_xl2_train_step_parity(hip, tag, prefer):
         loss_r = model.edm_loss(batch["image_latents"].cuda(), cond, mask_ratio=ratio, _noise=noise)
     torch.cuda.synchronize()
     drift_r = _block_drift(eng.last_tape, o["taps"], cfg)
+    gain_r = _block_drift(eng.last_tape, o["taps"], cfg, fn=_gain)
+    F_hip = eng.sample_image(eng.last_tape).float().cpu()
+    F_rep = {"rel_rms": _rel_rms(F_hip, o["taps"]["F"]), "gain": _gain(F_hip, o["taps"]["F"]),
+             "per_sample_gain": [_gain(F_hip[i], o["taps"]["F"][i]) for i in range(F_hip.shape[0])]}
     eng.route_override = None
     mixer_keys = [k for k in drift if k.startswith("patch_mixer")]
     every4 = mixer_keys[-1:] + [k for k in drift if k.startswith("blocks.") and int(k.split(".")[1]) % 4 == 3]
@@ -218,6 +228,8 @@ def test_xl2_train_step_parity(hip, tag, prefer):
            "loss_hip_oracle_routing": loss_r.item(), "loss_rel_diff_oracle_routing": (loss_r.item() - o["loss"]) / o["loss"],
            "gnorm_hip": gn_h, "gnorm_oracle": gn_o,
            "cosine": dot / (gn_h * gn_o), "gemm_launches": len(eng.gemm_log), "variants_requested": sorted(used),
+           "network_output_F_oracle_routing": F_rep,
+           "residual_stream_gain_oracle_routing": {k: gain_r[k] for k in every4},
            "residual_stream_rel_rms": {k: drift[k] for k in every4},
            "residual_stream_rel_rms_oracle_routing": {k: drift_r[k] for k in every4},
            "residual_stream_rel_rms_all": drift, "residual_stream_rel_rms_all_oracle_routing": drift_r,

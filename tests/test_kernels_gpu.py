@@ -92,8 +92,12 @@ def test_qkln(hip, width):
     ref_in = buf.float().clone().requires_grad_(True)
     rstd = torch.empty(2, rows, device=DEV)
     work = buf.clone()
-    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, 0, width, rstd[0].data_ptr(), 1e-6, st), "qkln q")
-    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, width, width, rstd[1].data_ptr(), 1e-6, st), "qkln k")
+    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, 0, width, 1, 0, rstd[0].data_ptr(), 1e-6, st), "qkln q")
+    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, width, width, 1, 0, rstd[1].data_ptr(), 1e-6, st), "qkln k")
+    work2, rstd2 = buf.clone(), torch.empty(2, rows, device=DEV)          # both halves in ONE launch: bit-identical to the two
+    hip.check(L.md_qkln_fwd(work2.data_ptr(), rows, ld, 0, width, 2, width, rstd2.data_ptr(), 1e-6, st), "qkln q+k")
+    torch.cuda.synchronize()
+    assert torch.equal(work2, work) and torch.equal(rstd2, rstd)
     q = F.layer_norm(ref_in[:, :width], (width,), None, None, 1e-6)
     k = F.layer_norm(ref_in[:, width:2 * width], (width,), None, None, 1e-6)
     torch.cuda.synchronize()
@@ -104,9 +108,12 @@ def test_qkln(hip, width):
     (q * d[:, :width].float()).sum().backward(retain_graph=True)
     (k * d[:, width:2 * width].float()).sum().backward()
     dwork = d.clone()
-    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, 0, work.data_ptr(), ld, 0, rows, width, rstd[0].data_ptr(), st), "b")
-    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, width, work.data_ptr(), ld, width, rows, width, rstd[1].data_ptr(), st), "b")
+    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, 0, work.data_ptr(), ld, 0, rows, width, 1, 0, 0, rstd[0].data_ptr(), st), "b")
+    hip.check(L.md_qkln_bwd(dwork.data_ptr(), ld, width, work.data_ptr(), ld, width, rows, width, 1, 0, 0, rstd[1].data_ptr(), st), "b")
+    dwork2 = d.clone()
+    hip.check(L.md_qkln_bwd(dwork2.data_ptr(), ld, 0, work.data_ptr(), ld, 0, rows, width, 2, width, width, rstd.data_ptr(), st), "b2")
     torch.cuda.synchronize()
+    assert torch.equal(dwork2, dwork)
     close(dwork[:, :2 * width], ref_in.grad[:, :2 * width], rel=3e-2, what="qkln bwd")
 
 
@@ -475,6 +482,22 @@ def test_gemm_operand_lists(hip):
     assert chosen == [hip.GEMM_PP256]
     ref = 1.0 + sum(dm[i].float() @ Ws[i].float() for i in range(G))
     close(out, ref, rel=2e-3, what="sum over operand-list items")
+    # ---- list_segments: ONE item walks G operand pairs and keeps the sum in its accumulators (K-concatenation), optionally
+    # split over groups of segments
+    Mc, Kk, G2 = 640, 256, 6
+    dk = bf(torch.randn(G2, Mc, Kk, device=DEV))
+    Wk = [bf(torch.randn(Kk, D, device=DEV) / math.sqrt(Kk * G2)) for _ in range(G2)]
+    al2 = torch.tensor([dk[i].data_ptr() for i in range(G2)], dtype=torch.int64).to(DEV)
+    bl2 = torch.tensor([w_.data_ptr() for w_ in Wk], dtype=torch.int64).to(DEV)
+    ref2 = sum(dk[i].float() @ Wk[i].float() for i in range(G2))
+    for ks2 in (1, 2, 3):
+        ws2 = torch.empty(ks2, Mc, D, device=DEV)
+        hip.gemm(A=dk, B=Wk[0], C=ws2, M=Mc, N=D, K=Kk * G2, lda=Kk, ldb=D, ldc=D, sC=ks2 * Mc * D, sSplit=Mc * D, ksplit=ks2,
+                 a_kcontig=1, b_kcontig=0, mode=hip.EPI_STORE_F32, A_list=al2, B_list=bl2, list_segments=G2 // ks2)
+        out2 = torch.zeros(Mc, D, device=DEV)
+        hip.check(L.md_splitk_reduce(ws2.data_ptr(), out2.data_ptr(), Mc, D, D, 0, ks2, 1, 1, st), "reduce")
+        torch.cuda.synchronize()
+        close(out2, ref2, rel=2e-3, what=f"K-concatenated operand lists, ksplit {ks2}")
     # lists on a kernel that is not built for them are refused as a bad argument, not silently ignored
     C = torch.empty(Bm, D, device=DEV, dtype=torch.bfloat16)
     assert hip.gemm(A=dm, B=Ws[0], C=C, M=Bm, N=D, K=kspan, lda=N, ldb=D, ldc=D, a_kcontig=1, b_kcontig=0, A_list=al, B_list=bl,

@@ -63,10 +63,7 @@ def train(cfg: dict):
     opt = FusedAdamW(model.dit, lr=ocfg["lr"], betas=tuple(ocfg.get("betas", (0.9, 0.999))), eps=ocfg.get("eps", 1e-8),
                      weight_decay=ocfg.get("weight_decay", 0.0), **ema_kw)
     if carried_opt is not None:
-        if carried_opt["m"].numel() != opt.m.numel():
-            raise RuntimeError(f"optimizer state of {cfg['trainer']['load_path']} has {carried_opt['m'].numel()} elements, "
-                               f"the model has {opt.m.numel()}")
-        opt.load_state_dict(carried_opt)
+        opt.load_state_dict(carried_opt)          # keyed by parameter name; raises on a mismatch with this model
     max_ba = parse_batches(cfg["trainer"]["max_duration"])
     scfg = dict(cfg["scheduler"])
     sched = LRSchedule.from_target(scfg.pop("_target_"), t_max=max_ba, **scfg)
@@ -116,6 +113,7 @@ def train(cfg: dict):
     for step, batch in zip(range(start, max_ba), loader):
         loss = trainer.train_step(batch)
         if eval_loader is not None and (step + 1) % eval_every == 0:
+            trainer.consolidate()                                  # sharded optimiser: whole fp32 weights / EMA on every rank
             ev = evaluate(model, eval_loader, world, microbatch=trainer.microbatch_size, opt=opt)
             if rank == 0:
                 print(json.dumps({"batch": step + 1, "metrics/eval/loss": ev}), flush=True)
@@ -128,6 +126,8 @@ def train(cfg: dict):
             dt, t_last = time.time() - t_last, time.time()
             print(json.dumps({"batch": step + 1, "loss": float(loss), "lr": opt.lr * sched.factor(step),
                               "samples_per_sec": ds["train_batch_size"] * log_every / dt}), flush=True)
+        if folder and save_every and (step + 1) % save_every == 0:
+            trainer.consolidate()                                  # a collective under the sharded optimiser: every rank calls it
         if rank == 0 and folder and save_every and (step + 1) % save_every == 0:
             os.makedirs(folder, exist_ok=True)
             tmp = os.path.join(folder, "latest.pt.tmp")
