@@ -45,6 +45,18 @@ enum md_epilogue {
 /* C[m,n] (+)= alpha * sum_k A(m,k) * B(n,k).  a_kcontig: A(m,k) = A[m*lda + k], else A[k*lda + m]; same for B
  * with n.  Replaces nn.Linear / einsum GEMMs: dit.py:84-89 (SwiGLU), dit.py:131-142 (MoE experts, batch = 8
  * experts), dit.py:222-225 (adaLN), utils.py:58-61, 109-111, 172-173, 225-233, and their autograd backward. */
+/* One problem of a grouped launch (md_gemm_args.problems): C_p[M, N] = A_p B_p^T with the launch's K, ksplit and operand layouts.
+ * The fp32 result of split s goes to C + s * sSplit + c_off (dense rows of N): the slices of a group mirror the layout of the
+ * gradient tensors they are reduced into, so ONE md_splitk_reduce_flat call per contiguous run finishes the whole group. */
+typedef struct md_gemm_problem {
+    const void* A;
+    const void* B;
+    int64_t lda, ldb;
+    int64_t M, N;
+    int64_t c_off;   /* elements, multiple of 4 */
+} md_gemm_problem;
+#define MD_GEMM_MAX_PROBLEMS 8
+
 typedef struct md_gemm_args {
     const void* A;      /* bf16 */
     const void* B;      /* bf16 */
@@ -82,6 +94,12 @@ typedef struct md_gemm_args {
     const void* const* A_list;
     const void* const* B_list;
     int32_t list_segments;   /* 0 or 1 = one pair per item */
+    /* Grouped launch (PP256, both operands K-strided, MD_EPI_STORE_F32 slices: the weight gradients of one DiT block that
+     * contract over the same tokens -- qkv, proj, q_linear, ... -- as ONE launch instead of one launch + one reduction each,
+     * every one of them too small to fill the chip without a deep split).  HOST array of n_problems <= MD_GEMM_MAX_PROBLEMS
+     * entries; A / B / M / N / lda / ldb / sC of the struct are ignored, K / ksplit / sSplit are shared. */
+    const md_gemm_problem* problems;
+    int32_t n_problems;
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot
@@ -100,6 +118,10 @@ int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);
 /* out[b] (+)= sum over the ksplit dense fp32 [M, N] slices a split-K md_gemm_bf16 left in ws (deterministic). */
 int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo, int64_t sOut, int32_t ksplit,
                      int32_t batch, int32_t accumulate, hipStream_t stream);
+
+/* out[i] (+)= sum_s ws[s * slice_stride + i], i < n: the flat form for grouped launches (n % 4 == 0). */
+int md_splitk_reduce_flat(const float* ws, float* out, int64_t n, int64_t slice_stride, int32_t ksplit, int32_t accumulate,
+                          hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- LayerNorm */
 /* y = LN(act(x + pos[row % pos_rows])) * w;  out = y * (1 + scale[row / rows_per_sample]) + shift[...].

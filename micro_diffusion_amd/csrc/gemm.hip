@@ -544,11 +544,11 @@ __device__ __forceinline__ float4 nt_ld4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo,
-                                                            int64_t sOut, int ksplit, int batch, int accumulate) {
-    const int64_t n4 = N / 4, per = M * n4, total = per * batch, slice = M * N;
+                                                            int64_t sOut, int ksplit, int batch, int accumulate, int64_t slice) {
+    const int64_t n4 = N / 4, per = M * n4, total = per * batch;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / per, r = i % per, m = r / n4, c = (r % n4) * 4;
-        const float* src = ws + ((b * ksplit) * M + m) * N + c;
+        const float* src = ws + (b * ksplit) * slice + m * N + c;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int s = 0;
         for (; s + 4 <= ksplit; s += 4) {
@@ -578,7 +578,18 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
     int64_t grid = (M * (N / 4) * batch + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, M, N, ldo, sOut, ksplit, batch,
-                       accumulate);
+                       accumulate, M * N);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_splitk_reduce_flat(const float* ws, float* out, int64_t n, int64_t slice_stride, int32_t ksplit, int32_t accumulate,
+                                     hipStream_t stream) {
+    if (!ws || !out || n <= 0 || n % 4 || slice_stride < n || slice_stride % 4 || ksplit <= 0) return MD_BAD_ARG;
+    int64_t grid = (n / 4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, (int64_t)1, n, n, (int64_t)0, ksplit, 1,
+                       accumulate, slice_stride);
     MD_LAUNCH_CHECK();
     return 0;
 }
@@ -587,6 +598,12 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (!a_in) return MD_BAD_ARG;
     md_gemm_args a_copy = *a_in;                     // raster_group_n is filled in below
     const md_gemm_args* a = &a_copy;
+    if (a->problems) {            // grouped launch: pp256 or nothing; A / B / M / N / leading dimensions come from the problem table
+        if (!a->C || a->K <= 0 || a->ksplit <= 0 || a->mode != MD_EPI_STORE_F32 || a->sSplit <= 0 || !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
+        if (a->variant != MD_GEMM_AUTO && a->variant != MD_GEMM_PP256) return MD_NOT_ELIGIBLE;
+        if (a->chosen_variant) *a->chosen_variant = MD_GEMM_PP256;
+        return md_gemm_pp_launch(a, stream);
+    }
     if (!a->A || !a->B || !a->C) return MD_BAD_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->ksplit <= 0) return MD_BAD_ARG;
     // All global accesses are 16-byte chunks of 8 bf16 along the contiguous dimension: leading dimensions must be

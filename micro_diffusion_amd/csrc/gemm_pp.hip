@@ -107,12 +107,12 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
     constexpr bool F32OUT = (EPI == PP_E_F32);
     constexpr int ES = F32OUT ? 4 : 2;
     constexpr int CW = F32OUT ? 4 : 8;                              // columns per store
-    const unsigned ldc = (unsigned)p.ldc;
+    const unsigned ldc = (unsigned)et.ldc;
     int l = el.lane;
     asm volatile("" : "+v"(l));                                   // recomputed per quadrant, not kept across the main loop
     const int rl = el.wrow + (l & 31) + IH * 128;                 // row / first column inside the tile
     const int cl = el.wcol + (l >> 5) * CW + JH * 128;
-    const int mlim = w.M - et.m0, nlim = w.N - et.n0;
+    const int mlim = et.M - et.m0, nlim = et.N - et.n0;
     const float alpha = p.alpha;
     if constexpr (F32OUT) {
         // fp32 slices (weight gradients, long K): stored straight from the accumulator layout -- a lane's 4 consecutive columns are 16 bytes
@@ -212,9 +212,24 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
 }
 
 // Called (by every lane, all values wave-uniform) when a tile's k-loop ends: where its outputs and epilogue operands live.
-template <int EPI>
+template <int EPI, bool GROUPABLE>
 __device__ __forceinline__ void epi_open(const md_gemm_args& p, const PPPlan& w, EpiTile& et) {
     constexpr bool F32OUT = (EPI == PP_E_F32);
+    et.M = w.M;
+    et.N = w.N;
+    et.ldc = (int)p.ldc;
+    if (GROUPABLE && w.nprob) {                 // grouped launch: this tile belongs to problem et.q; dense rows of N inside the slice
+        const PPProblem& pr = w.prob[et.q];
+        et.M = pr.M;
+        et.N = pr.N;
+        et.ldc = pr.N;
+        et.cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.split * p.sSplit + pr.c_off, et, pr.N, 4));
+        et.c2base = nullptr;
+        et.opbase = nullptr;
+        et.gbase = nullptr;
+        et.plain = !p.bias && p.alpha == 1.f && et.m0 + PT <= et.M && et.n0 + PT <= et.N;
+        return;
+    }
     et.cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.batch * p.sC + (F32OUT ? (int64_t)et.split * p.sSplit : 0), et, p.ldc, F32OUT ? 4 : 2));
     et.c2base = (!F32OUT && EPI != PP_E_DACT_GELU && p.C2) ? const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2)) : nullptr;
     et.opbase = EPI == PP_E_RES        ? tile_base(p.res, 0, et, p.ldr, 2)
@@ -256,8 +271,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     unsigned adA[4], adB[4];
     frag_addrs<AKC>(adA, lds0, wr * 64, lane);
     frag_addrs<BKC>(adB, lds0 + B_REGION, wc * 32, lane);
-    const int64_t a_kstep = AKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.lda * 2;   // bytes per k-tile
-    const int64_t b_kstep = BKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.ldb * 2;
+    // grouped launches (several problems, md_gemm_args.problems) exist for the weight-gradient kernel only (both operands
+    // K-strided, fp32 slices); every other instantiation keeps its code unchanged
+    constexpr bool GROUPABLE = !AKC && !BKC && EPI == PP_E_F32;
+    int64_t a_kstep = AKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.lda * 2;   // bytes per k-tile (per problem in a grouped launch)
+    int64_t b_kstep = BKC ? (int64_t)BKT * 2 : (int64_t)BKT * w.ldb * 2;
     const EpiLane el = {lane, wr * 64, wc * 32};
 
     // ---- stager (DMA prefetch) cursor
@@ -275,6 +293,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     };
     auto stager_open = [&](int n) {                // point the stager at item ordinal n
         int m0, n0, batch, split;
+        if (GROUPABLE && w.nprob) {                // grouped launch: the item's problem supplies operands, extents, leading dimensions
+            int q;
+            work_decode_grouped(w, w_first + n * w_stride, q, m0, n0, split);
+            const PPProblem& pr = w.prob[q];
+            stage_offsets<AKC>(aofs, m0, pr.M, pr.lda, wave, lane);
+            stage_offsets<BKC>(bofs, n0, pr.N, pr.ldb, wave, lane);
+            a_kstep = (int64_t)BKT * pr.lda * 2;
+            b_kstep = (int64_t)BKT * pr.ldb * 2;
+            const int64_t kb = (int64_t)split * w.kspan;
+            sA = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(pr.A) + kb * pr.lda + m0);
+            sB = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(pr.B) + kb * pr.ldb + n0);
+            return;
+        }
         work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
         stage_offsets<AKC>(aofs, m0, w.M, w.lda, wave, lane);
         stage_offsets<BKC>(bofs, n0, w.N, w.ldb, wave, lane);
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     int c_n = 0, c_kt = 0;
     bool epi_pending = false;
     int pf_after = 0;                              // DMA instructions issued after the pending operand prefetch
-    EpiTile et = {0, 0, 0, 0, false, nullptr, nullptr, nullptr, nullptr};
+    EpiTile et = {0, 0, 0, 0, 0, 0, 0, 0, false, nullptr, nullptr, nullptr, nullptr};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the epilogues with prefetched operands are built in the PLAIN form only (two copies of their quadrant body do not fit
     // the register budget); md_gemm_pp_eligible sends their ragged / biased / scaled problems to the gemm.hip kernels
@@ -483,8 +514,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         PP_COMPUTE(3, fb1, PP_PIN_A(), false);
         // phase 8: on the last k-tile pair of an output tile, request the operands of the first epilogue quadrant
         if (last_pair) {
-            work_decode(w, w_first + c_n * w_stride, et.m0, et.n0, et.batch, et.split);
-            epi_open<EPI>(p, w, et);
+            if (GROUPABLE && w.nprob) {
+                work_decode_grouped(w, w_first + c_n * w_stride, et.q, et.m0, et.n0, et.split);
+                et.batch = 0;
+            } else {
+                work_decode(w, w_first + c_n * w_stride, et.m0, et.n0, et.batch, et.split);
+            }
+            epi_open<EPI, GROUPABLE>(p, w, et);
             if (has_ops) epi_prefetch<EPI, 0, 0>(p, w, et, pre, el);
         }
         {
@@ -563,6 +599,15 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     if (kspan < 128 || kspan % 128) return false;
     if (a->N % 8) return false;                                  // 16-byte column chunks everywhere
     if ((a->A_list || a->B_list) && epi != PP_E_F32) return false;   // operand lists are built into the fp32-slice kernels only
+    if (a->problems || a->n_problems) {                              // grouped launch: the weight-gradient kernel only
+        if (!a->problems || a->n_problems < 1 || a->n_problems > MD_GEMM_MAX_PROBLEMS) return false;
+        if (a->a_kcontig || a->b_kcontig || epi != PP_E_F32 || a->A_list || a->bias || a->alpha != 1.f || a->batch != 1) return false;
+        for (int i = 0; i < a->n_problems; ++i) {
+            const md_gemm_problem& s = a->problems[i];
+            if (!s.A || !s.B || s.M <= 0 || s.N <= 0 || s.N % 8 || s.lda % 8 || s.ldb % 8 || s.c_off % 4 || s.c_off < 0) return false;
+            if (s.lda > (1 << 22) || s.ldb > (1 << 22) || s.N > (1 << 20) || s.M >= (1 << 30)) return false;
+        }
+    }
     if (a->A_list && a->list_segments > 1 && (kspan % ((int64_t)a->list_segments * 128))) return false;   // whole k-tile pairs per segment
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
     if ((epi == PP_E_RES || epi == PP_E_DACT_GELU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))

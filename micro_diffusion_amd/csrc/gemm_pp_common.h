@@ -118,8 +118,17 @@ __device__ __forceinline__ void stage_half(const char* base, const unsigned (&of
 // time form a (32 / group_n) x group_n block of the output that shares A row-panels and B column-panels in L2.
 // The plan is computed on the host (md_gemm_pp_launch) and passed by value.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int PP_MAX_PROB = MD_GEMM_MAX_PROBLEMS;
+struct PPProblem {                 // one problem of a grouped launch (md_gemm_args.problems), everything the kernel needs of it
+    const void* A;
+    const void* B;
+    int64_t c_off;                 // elements into every fp32 slice
+    int lda, ldb, M, N;
+    int ntm, ntn, tile0, group_n;  // tiles, first global tile id, raster group
+};
+
 struct PPPlan {
-    int ntm, ntn, ntiles, total;   // tiles per problem; items in total
+    int ntm, ntn, ntiles, total;   // tiles per problem (grouped: ntiles = all problems' tiles); items in total
     int nk;                        // k-tiles (64 deep) per item, even
     int kspan;                     // elements of K per split
     int group_n;                   // column-tiles per raster group
@@ -127,6 +136,8 @@ struct PPPlan {
     int lda, ldb;
     int rps_shift;                 // log2(rows_per_sample) when that is a power of two, else -1 (gated residual only)
     int nseg, nk_seg;              // operand lists: segments per item and k-tiles per segment (nseg <= 1: one operand pair per item)
+    int nprob;                     // grouped launch: number of problems (0 = the single problem of md_gemm_args)
+    PPProblem prob[PP_MAX_PROB];
 };
 
 __device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, int& n0, int& batch, int& split) {
@@ -138,6 +149,27 @@ __device__ __forceinline__ void work_decode(const PPPlan& w, int item, int& m0, 
     const unsigned g = t / per_group, rem = t - g * per_group;
     const int first_n = (int)g * w.group_n;
     const int gn = (w.ntn - first_n) < w.group_n ? (w.ntn - first_n) : w.group_n;
+    const unsigned tm = rem / (unsigned)gn;
+    m0 = (int)tm * PT;
+    n0 = (first_n + (int)(rem - tm * (unsigned)gn)) * PT;
+}
+
+// Grouped launch: item -> (problem q, tile origin, split).  Items are split-major (y = item / all tiles), tiles of a problem
+// rastered like a single problem's.  All values wave-uniform (scalar loop over <= 8 problems).
+__device__ __forceinline__ void work_decode_grouped(const PPPlan& w, int item, int& q, int& m0, int& n0, int& split) {
+    const unsigned y = (unsigned)item / (unsigned)w.ntiles;
+    const int t = (int)((unsigned)item - y * (unsigned)w.ntiles);
+    split = (int)y;
+    q = 0;
+#pragma unroll 1
+    for (int i = 1; i < w.nprob; ++i)
+        if (t >= w.prob[i].tile0) q = i;
+    const PPProblem& pr = w.prob[q];
+    const unsigned tl = (unsigned)(t - pr.tile0);
+    const unsigned per_group = (unsigned)(pr.group_n * pr.ntm);
+    const unsigned g = tl / per_group, rem = tl - g * per_group;
+    const int first_n = (int)g * pr.group_n;
+    const int gn = (pr.ntn - first_n) < pr.group_n ? (pr.ntn - first_n) : pr.group_n;
     const unsigned tm = rem / (unsigned)gn;
     m0 = (int)tm * PT;
     n0 = (first_n + (int)(rem - tm * (unsigned)gn)) * PT;
@@ -155,6 +187,7 @@ enum {
 
 struct EpiTile {
     int m0, n0, batch, split;
+    int q, M, N, ldc;      // grouped launch: problem index; extent and leading dimension of the output this tile belongs to
     // filled by epi_open() when the tile's k-loop finishes (all wave-uniform):
     bool plain;            // interior tile, no bias, alpha == 1: the short form of the epilogue
     char* cbase;           // &C[batch, (split,) m0, n0]
@@ -321,10 +354,31 @@ inline int md_gemm_pp_epi_kind(const md_gemm_args* a) {
 
 
 inline bool md_gemm_pp_plan(const md_gemm_args* a, PPPlan* w) {
+    w->nprob = 0;
     w->ntm = (int)((a->M + PT - 1) / PT);
     w->ntn = (int)((a->N + PT - 1) / PT);
     w->ntiles = w->ntm * w->ntn;
-    const int64_t total = (int64_t)w->ntiles * a->batch * a->ksplit;
+    if (a->problems && a->n_problems > 0) {
+        w->nprob = a->n_problems;
+        int t0 = 0;
+        const int64_t kspan_ = a->K / a->ksplit;
+        for (int i = 0; i < a->n_problems; ++i) {
+            const md_gemm_problem& s = a->problems[i];
+            PPProblem& d = w->prob[i];
+            d.A = s.A; d.B = s.B; d.c_off = s.c_off;
+            d.lda = (int)s.lda; d.ldb = (int)s.ldb; d.M = (int)s.M; d.N = (int)s.N;
+            d.ntm = (int)((s.M + PT - 1) / PT);
+            d.ntn = (int)((s.N + PT - 1) / PT);
+            d.tile0 = t0;
+            int64_t g = (2 << 20) / (PT * kspan_ * 2);      // same L2 raster rule as a single problem (md_gemm_bf16)
+            if (g < 4) g = 4;
+            if (g > d.ntn) g = d.ntn;
+            d.group_n = (int)g;
+            t0 += d.ntm * d.ntn;
+        }
+        w->ntiles = t0;
+    }
+    const int64_t total = (int64_t)w->ntiles * (w->nprob ? 1 : a->batch) * a->ksplit;
     if (total > (1 << 30)) return false;
     w->total = (int)total;
     w->kspan = (int)(a->K / a->ksplit);

@@ -125,6 +125,9 @@ class DiTEngine:
         self._ptr_cache = {}
         self.ksplit_min_items = 192  # work items a split-K factor must reach (A/B: 128 = the round-2 rule)
         self.splitk_force_pp = False  # A/B: force pp256 for every split-K launch it accepts, whatever the tile count
+        self.group_wgrad = True     # the weight gradients of a block that contract over the same tokens as grouped launches (A/B: False)
+        self._wgroup = None
+        self.single_slice_ws = True  # launches with >= 192 tiles of their own: one fp32 slice through the workspace on pp256 (A/B: False = accumulate epilogue)
         self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
@@ -169,6 +172,7 @@ class DiTEngine:
 
     def _gemm(self, **kw):
         a = hip.GemmArgs()
+        problems = kw.pop("_problems", None)      # grouped launch: the problem dicts (accounting only; the table is in kw["problems"])
         for k, v in kw.items():
             setattr(a, k, v)
         prof = self.gemm_profile
@@ -196,7 +200,14 @@ class DiTEngine:
             mn = a.M * a.N * a.batch
             byt = 2.0 * (a.M * a.K + a.N * a.K) * a.batch + mn * out_b * a.ksplit
             byt += mn * 2 * ((1 if a.C2 else 0) + (1 if a.res else 0) + (1 if a.aux else 0)) + (mn * 4 if a.mode == hip.EPI_ACCUM_F32 else 0)
-            prof.append((e0, e1, 2.0 * a.M * a.N * a.K * a.batch, (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit), byt))
+            fl = 2.0 * a.M * a.N * a.K * a.batch
+            key = (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit)
+            if problems:
+                mn = sum(g["M"] * g["N"] for g in problems)
+                fl = 2.0 * mn * a.K
+                byt = 2.0 * a.K * sum(g["M"] + g["N"] for g in problems) + mn * 4 * a.ksplit
+                key = (-len(problems), mn // 1024, a.K, 1, 0, 0, a.ksplit)
+            prof.append((e0, e1, fl, key, byt))
 
     def lin_fwd(self, x, wname, out, M, N, K, *, ldx=None, ldc=None, mode=hip.EPI_STORE_BF16, act=0, res=None,
                 gate=None, ldg=0, rps=0, C2=None, ldc2=0, xoff=0, ooff=0, bias=True):
@@ -238,7 +249,10 @@ class DiTEngine:
             units = contraction // 128
             out_us = out_rows * out_cols * batch * 4 / 4e6
             best, best_cost = None, None
-            for ks in range(2, min(64, ws_cap, units) + 1):
+            # ks = 1 is a candidate too: a launch with enough tiles of its own (the 8-expert weight gradients) writes ONE fp32
+            # slice to the workspace and the reduction pass adds it to the accumulator -- 3 passes over the output instead of the
+            # 2 slices + 4 passes the smallest split costs, on the persistent kernel instead of the 2-stage accumulate epilogue
+            for ks in range(1, min(64, ws_cap, units) + 1):
                 if units % ks or t256 * ks < getattr(self, "ksplit_min_items", 192):   # md_gemm_bf16's AUTO rule sends
                     continue                                                           # < 192 tiles to the 2-stage kernels
                 per_wg = -(-t256 * ks // 256)
@@ -246,7 +260,7 @@ class DiTEngine:
                 if best_cost is None or cost < best_cost:
                     best, best_cost = ks, cost
             if best is not None:
-                return best
+                return best if best > 1 else -1          # -1: one slice through the workspace (pp256), not the accumulate epilogue
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * batch
         ks = max(1, self.wgrad_target_blocks // tiles)
         ks = min(ks, max(1, contraction // 512))
@@ -256,7 +270,10 @@ class DiTEngine:
         """fp32 C (+)= A B^T with automatic split-K: partial products go to a workspace as dense fp32 slices and are
         summed by md_splitk_reduce (deterministic; float atomics measured 4-10x slower on this shape class)."""
         ks = self._ksplit(M, N, K, batch)
-        if ks == 1:
+        via_ws = ks != 1
+        if ks == -1:                      # enough tiles without splitting: one slice through the workspace on pp256
+            ks, via_ws = 1, self.single_slice_ws
+        if not via_ws:
             self._gemm(C=out_ptr, M=M, N=N, K=K, ldc=ldo, sC=sOut, batch=batch, ksplit=1,
                        mode=hip.EPI_ACCUM_F32 if accumulate else hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
             return
@@ -264,20 +281,89 @@ class DiTEngine:
             operands = dict(operands, variant=hip.GEMM_PP256)
         self._gemm(C=self.ws.data_ptr(), M=M, N=N, K=K, ldc=N, sC=ks * M * N, sSplit=M * N, batch=batch, ksplit=ks,
                    mode=hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
-        hip.check(self.L.md_splitk_reduce(self.ws.data_ptr(), out_ptr, M, N, ldo, sOut, ks, batch, 1 if accumulate else 0,
-                                          self._st()), "md_splitk_reduce")
+        self._prof("splitk_reduce", 4.0 * M * N * batch * (ks + (2 if accumulate else 1)), lambda: hip.check(
+            self.L.md_splitk_reduce(self.ws.data_ptr(), out_ptr, M, N, ldo, sOut, ks, batch, 1 if accumulate else 0, self._st()),
+            "md_splitk_reduce"))
 
-    def lin_wgrad(self, dy, x, wname, M, N, K, *, lddy=None, ldx=None, dyoff=0, xoff=0, bias_from=None):
+    def lin_wgrad(self, dy, x, wname, M, N, K, *, lddy=None, ldx=None, dyoff=0, xoff=0, bias_from=None, defer=False):
         """grad W[N,K] += dy[M,N]^T @ x[M,K]  (both operands K-strided; split-K over the token dimension);
-        grad b[N] += column sums of dy."""
-        self.gemm_f32_acc(out_ptr=self.G[wname + ".weight"].data_ptr(), M=N, N=K, K=M, ldo=K,
-                          A=dy.data_ptr() + 2 * dyoff, B=x.data_ptr() + 2 * xoff, lda=lddy or N, ldb=ldx or K,
-                          a_kcontig=0, b_kcontig=0)
+        grad b[N] += column sums of dy.
+        defer: with a weight-gradient group open (_wgrad_begin), only record the problem -- the whole group runs as ONE grouped
+        launch at _wgrad_flush().  The caller guarantees that dy and x are not modified before the flush."""
         gb = self.G.get(wname + ".bias")
         if gb is not None:
             src = dy if bias_from is None else bias_from
             hip.check(self.L.md_colsum(src.data_ptr() + (0 if bias_from is not None else 2 * dyoff),
                                        1 if src.dtype == F32 else 0, lddy or N, gb.data_ptr(), M, N, self._st()), "colsum")
+        grp = self._wgroup
+        if defer and grp is not None and M % 128 == 0 and K % 8 == 0 and (not grp or grp[0]["tokens"] == M) and len(grp) < hip.GEMM_MAX_PROBLEMS:
+            grp.append(dict(tokens=M, A=dy.data_ptr() + 2 * dyoff, lda=lddy or N, B=x.data_ptr() + 2 * xoff, ldb=ldx or K, M=N, N=K,
+                            out=self.G[wname + ".weight"].data_ptr(), keep=(dy, x)))
+            return
+        self.gemm_f32_acc(out_ptr=self.G[wname + ".weight"].data_ptr(), M=N, N=K, K=M, ldo=K,
+                          A=dy.data_ptr() + 2 * dyoff, B=x.data_ptr() + 2 * xoff, lda=lddy or N, ldb=ldx or K,
+                          a_kcontig=0, b_kcontig=0)
+
+    def _wgrad_begin(self):
+        self._wgroup = [] if self.group_wgrad else None
+
+    def _wgrad_flush(self):
+        """Run the recorded weight gradients (same token count) as ONE grouped pp256 launch: their output tiles share the 256
+        workgroups, so the split over the tokens only has to fill what ALL of them leave empty (ks = 2..8 instead of 8..16 each),
+        the fp32 slices mirror the layout of the gradient tensors, and one flat reduction per contiguous run finishes them."""
+        grp, self._wgroup = self._wgroup, ([] if self._wgroup is not None else None)
+        if not grp:
+            return
+        if len(grp) == 1:
+            g = grp[0]
+            self.gemm_f32_acc(out_ptr=g["out"], M=g["M"], N=g["N"], K=g["tokens"], ldo=g["N"], A=g["A"], B=g["B"], lda=g["lda"],
+                              ldb=g["ldb"], a_kcontig=0, b_kcontig=0)
+            return
+        grp.sort(key=lambda g: g["out"])
+        base = grp[0]["out"]
+        span = max(g["out"] + 4 * g["M"] * g["N"] for g in grp) - base
+        span_el = span // 4
+        tokens = grp[0]["tokens"]
+        units = tokens // 128
+        t256 = sum(((g["M"] + 255) // 256) * ((g["N"] + 255) // 256) for g in grp)
+        out_us = sum(g["M"] * g["N"] for g in grp) * 4 / 4e6
+        ws_cap = self.ws.numel() // span_el
+        best, best_cost = None, None
+        for ks in range(1, min(64, ws_cap, units) + 1):
+            if units % ks:
+                continue
+            per_wg = -(-t256 * ks // 256)
+            cost = per_wg * (tokens / ks / 64 * 1.9 + 5.0) + (ks + 2) * out_us
+            if t256 * ks < 192:
+                cost *= 192.0 / (t256 * ks)            # an under-filled chip: the round costs the same with fewer tiles done
+            if best_cost is None or cost < best_cost:
+                best, best_cost = ks, cost
+        if best is None:                                # does not fit the workspace: one by one
+            for g in grp:
+                self.gemm_f32_acc(out_ptr=g["out"], M=g["M"], N=g["N"], K=g["tokens"], ldo=g["N"], A=g["A"], B=g["B"], lda=g["lda"],
+                                  ldb=g["ldb"], a_kcontig=0, b_kcontig=0)
+            return
+        ks = best
+        probs = (hip.GemmProblem * len(grp))()
+        for i, g in enumerate(grp):
+            probs[i] = hip.GemmProblem(g["A"], g["B"], g["lda"], g["ldb"], g["M"], g["N"], (g["out"] - base) // 4)
+        g0 = grp[0]
+        self._gemm(A=g0["A"], B=g0["B"], C=self.ws.data_ptr(), M=g0["M"], N=g0["N"], K=tokens, lda=g0["lda"], ldb=g0["ldb"], ldc=g0["N"],
+                   sSplit=span_el, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0, mode=hip.EPI_STORE_F32, act=0, alpha=1.0,
+                   problems=ctypes.addressof(probs), n_problems=len(grp), _problems=grp)
+        # contiguous runs of gradient tensors -> one flat reduction each
+        runs, cur = [], [grp[0]["out"], grp[0]["out"] + 4 * grp[0]["M"] * grp[0]["N"]]
+        for g in grp[1:]:
+            if g["out"] == cur[1]:
+                cur[1] = g["out"] + 4 * g["M"] * g["N"]
+            else:
+                runs.append(cur)
+                cur = [g["out"], g["out"] + 4 * g["M"] * g["N"]]
+        runs.append(cur)
+        for lo, hi in runs:
+            n = (hi - lo) // 4
+            self._prof("splitk_reduce", 4.0 * n * (ks + 2), lambda lo=lo, n=n: hip.check(
+                self.L.md_splitk_reduce_flat(self.ws.data_ptr() + (lo - base), lo, n, span_el, ks, 1, self._st()), "md_splitk_reduce_flat"))
 
     def ln_args(self, x, wname, out, rows, C, *, shift=None, scale=None, ldmod=0, rps=0, mean=None, rstd=None, act=0,
                 pos=None, pos_rows=0):
@@ -347,7 +433,7 @@ class DiTEngine:
         t.qkv, t.rq, t.o, t.lse = qkv, rq, o, lse
         return o
 
-    def _self_attn_bwd(self, pre, xin, do, B, S, dim, hid, heads, t):
+    def _self_attn_bwd(self, pre, xin, do, B, S, dim, hid, heads, t, defer=False):
         """do [M, hid] -> returns d_xin [M, dim]; accumulates the qkv weight grad."""
         M, L, st = B * S, self.L, self._st()
         dqkv = self.empty(M, 3 * hid)
@@ -358,7 +444,7 @@ class DiTEngine:
                            dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
         self._attn_bwd(a)
         self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq.data_ptr(), nseg=2)
-        self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim)
+        self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim, defer=defer)
         dxin = self.empty(M, dim)
         self.lin_dgrad(dqkv, pre + ".qkv", dxin, M, 3 * hid, dim)
         return dxin
@@ -479,6 +565,7 @@ class DiTEngine:
         M, Mc, D = B * S, B * Lc, cfg.dim
         n = bp.name
         mp = t.mod.data_ptr()
+        self._wgrad_begin()
         dmod = self.zeros(B, 6 * d)          # fp32 grads of (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp)
         dmp = dmod.data_ptr()
         rpb = self._rows_per_block(M, S)
@@ -488,17 +575,17 @@ class DiTEngine:
                                 M, d, S, rpb, st), "gate_bwd")
         dxm3 = self.empty(M, d)
         if not bp.moe:
-            self.lin_wgrad(dbr3, t.a, n + ".mlp.w3", M, d, f)
+            self.lin_wgrad(dbr3, t.a, n + ".mlp.w3", M, d, f, defer=True)
             da = self.empty(M, f)
             self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
             dh12 = self.empty(M, 2 * f)
             hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd")
             if self._fused12(n + ".mlp"):
-                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, 2 * f, d)
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, 2 * f, d, defer=True)
                 self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, 2 * f, d)
             else:
-                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, f, d, lddy=2 * f)
-                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w2", M, f, d, lddy=2 * f, dyoff=f)
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, f, d, lddy=2 * f, defer=True)
+                self.lin_wgrad(dh12, t.xm3, n + ".mlp.w2", M, f, d, lddy=2 * f, dyoff=f, defer=True)
                 self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, f, d, lddy=2 * f)
                 self.lin_dgrad(dh12, n + ".mlp.w2", dxm3, M, f, d, lddy=2 * f, dyoff=f, mode=hip.EPI_RESIDUAL, res=dxm3)
         else:
@@ -534,7 +621,7 @@ class DiTEngine:
         a3 = self.ln_args(t.x2, n + ".norm3", None, M, d, scale=mp + 2 * 4 * d, ldmod=6 * d, rps=S, mean=t.st3[0], rstd=t.st3[1])
         self.ln_bwd(a3, dxm3, dx, accumulate=True, wname=n + ".norm3", dscale=dmp + 4 * 4 * d, dshift=dmp + 4 * 3 * d, ldg=6 * d)
         # ---------------- cross-attention branch (un-gated, un-modulated)
-        self.lin_wgrad(dx, t.o2, n + ".cross_attn.proj", M, d, hx)
+        self.lin_wgrad(dx, t.o2, n + ".cross_attn.proj", M, d, hx, defer=True)     # dx stays as it is until the flush below
         do2 = self.empty(M, hx)
         self.lin_dgrad(dx, n + ".cross_attn.proj", do2, M, d, hx)
         dq2 = self.empty(M, hx)
@@ -546,7 +633,7 @@ class DiTEngine:
         self._attn_bwd(ax)
         self._qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr())
         self._qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr())
-        self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d)
+        self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d, defer=True)
         self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
         # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens: per block (split-K slices + a
         # reduction pass into the [B*L, d] fp32 buffer, 28 times), or -- kvgroup -- deferred: dkv of every block is kept and ONE
@@ -558,18 +645,21 @@ class DiTEngine:
             kvgroup["w"].append(self.S[n + ".cross_attn.kv_linear.weight"].data_ptr())
         dxn2 = self.empty(M, d)
         self.lin_dgrad(dq2, n + ".cross_attn.q_linear", dxn2, M, hx, d)
+        self._wgrad_flush()                  # w3, [w1; w2], cross_attn.proj, q_linear -- before dx (cross_attn.proj's dy) is updated
         a2 = self.ln_args(t.x1, n + ".norm2", None, M, d, mean=t.st2[0], rstd=t.st2[1], rps=S)
         self.ln_bwd(a2, dxn2, dx, accumulate=True, wname=n + ".norm2")
         # ---------------- self-attention branch
         dbr1 = self.empty(M, d)
         hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, 6 * d, dbr1.data_ptr(), dmp + 4 * 2 * d, 6 * d,
                                 M, d, S, rpb, st), "gate_bwd")
-        self.lin_wgrad(dbr1, t.sa.o, n + ".attn.proj", M, d, h)
+        self.lin_wgrad(dbr1, t.sa.o, n + ".attn.proj", M, d, h, defer=True)
         do = self.empty(M, h)
         self.lin_dgrad(dbr1, n + ".attn.proj", do, M, d, h)
-        dxm1 = self._self_attn_bwd(n + ".attn", t.xm1, do, B, S, d, h, bp.heads, t.sa)
+        dxm1 = self._self_attn_bwd(n + ".attn", t.xm1, do, B, S, d, h, bp.heads, t.sa, defer=True)
+        self._wgrad_flush()                  # attn.proj, attn.qkv
         a1 = self.ln_args(t.x, n + ".norm1", None, M, d, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
         self.ln_bwd(a1, dxm1, dx, accumulate=True, wname=n + ".norm1", dscale=dmp + 4 * d, dshift=dmp, ldg=6 * d)
+        self._wgroup = None
         # ---------------- adaLN linear: mod = W gelu(c) + b
         self._adaln_bwd(n + ".adaLN_modulation.1", dmod, B, 6 * d, gc, dgc_f32, group)
 
@@ -613,7 +703,7 @@ class DiTEngine:
             if G % ks or ks * Mc * d > self.ws.numel():
                 continue
             rounds = -(-t256 * ks // 256)
-            cost = rounds * ((G // ks) * K / 64 * 0.45 + 5.0) + (ks + 2) * out_us
+            cost = rounds * ((G // ks) * K / 64 * 1.9 + 5.0) + (ks + 2) * out_us
             if best_cost is None or cost < best_cost:
                 best, best_cost = ks, cost
         ks, S = best, G // best

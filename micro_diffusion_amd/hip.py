@@ -94,6 +94,13 @@ def _build_locked(force: bool, verbose: bool) -> str:
     return LIB_PATH
 
 
+class GemmProblem(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("lda", c_int64), ("ldb", c_int64), ("M", c_int64), ("N", c_int64), ("c_off", c_int64)]
+
+
+GEMM_MAX_PROBLEMS = 8
+
+
 class GemmArgs(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p),
@@ -107,6 +114,7 @@ class GemmArgs(Structure):
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
         ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p), ("list_segments", c_int32),
+        ("problems", c_void_p), ("n_problems", c_int32),
     ]
 
 
@@ -194,6 +202,7 @@ SUMSQ_PARTIALS = 1024    # MD_SUMSQ_PARTIALS
 
 
 _sig("md_gemm_bf16", POINTER(GemmArgs), P)
+_sig("md_splitk_reduce_flat", P, P, I64, I64, I32, I32, P)
 _sig("md_splitk_reduce", P, P, I64, I64, I64, I64, I32, I32, I32, P)
 _sig("md_ln_fwd", POINTER(LnArgs), P)
 _sig("md_ln_bwd", POINTER(LnArgs), POINTER(LnBwdArgs), P)
@@ -269,7 +278,7 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
-                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments)
+                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0)
     ch = ctypes.c_int32(-1)
     a.chosen_variant = ctypes.addressof(ch)
     rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())

@@ -14,13 +14,18 @@ batch = {"image_latents": (torch.randn(B, 4, 32, 32, device="cuda", generator=g)
          "caption_latents": torch.randn(B, 1, 77, 1024, device="cuda", generator=g).half(),
          "drop_caption_mask": torch.ones(B, device="cuda")}
 for _ in range(2):
-    model(batch)[0].backward()
+    model.train_microbatch(batch)
 torch.cuda.synchronize()
 eng = model.dit.engine
 eng.gemm_profile = []
+eng.kernel_profile = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); model(batch)[0].backward(); e1.record(); torch.cuda.synchronize()
+e0.record(); model.train_microbatch(batch); e1.record(); torch.cuda.synchronize()
 prof, eng.gemm_profile = eng.gemm_profile, None
+kprof, eng.kernel_profile = eng.kernel_profile, None
+for name, recs in kprof.items():
+    ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    print(f"{name:16s} {len(recs):5d} launches {ms:8.2f} ms  {sum(r[2] for r in recs) / ms / 1e9:7.2f} TB/s (algorithmic)")
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for a, b, fl, key, _ in prof:
     r = agg[key]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl

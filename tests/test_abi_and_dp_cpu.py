@@ -120,11 +120,15 @@ def test_splitk_factor_fills_whole_rounds():
     assert pick(1024, 1024, 65536, 1) == 16        # 16 tiles x 16 = 256 work items, one per CU
     assert pick(2048, 1024, 78848, 1) == 8         # 32 tiles x 8 = 256
     assert pick(1024, 1024, 16384, 1) == 16        # microbatch 256 (the per-rank shape of an 8-GPU run)
-    assert pick(78848, 1024, 2048, 1) == 1         # output larger than the workspace: accumulate in place
+    assert pick(78848, 1024, 2048, 1) == -1        # 1232 tiles of its own: no split, one slice through the workspace
+    assert pick(1024, 3840, 4096, 8) == -1         # the 8-expert weight gradient of a MoE block at microbatch 256: 480 tiles
     for shape in [(1024, 1024, 65536, 1), (768, 3072, 65536, 8), (16, 1024, 65536, 1), (256, 256, 1024, 1), (1024, 8, 512, 1),
                   (768, 768, 262144, 1), (5376, 1024, 65536, 1), (3072, 1024, 16384, 1), (6144, 1024, 1024, 1), (1024, 1024, 1000, 1)]:
         ks = pick(*shape)
         rows, cols, K, batch = shape
+        if ks == -1:                         # enough tiles without splitting: ONE slice through the workspace on pp256
+            assert ((rows + 255) // 256) * ((cols + 255) // 256) * batch >= 192 and K % 128 == 0
+            ks = 1
         assert 1 <= ks <= 64 and ks * rows * cols * batch <= (128 << 20)
         t256 = ((rows + 255) // 256) * ((cols + 255) // 256) * batch
         pp256_pick = ks > 1 and K % (128 * ks) == 0 and t256 * ks >= 192     # md_gemm_bf16's AUTO rule: >= 192 tiles run on pp256

@@ -43,8 +43,8 @@ def _build(world_batch_slice, exchange, microbatch, dp_mode="allreduce"):
     lo, hi = world_batch_slice
     calls = {"n": 0}
 
-    def noise_fn(B):                      # recorded draws, consumed microbatch by microbatch
-        a = lo + calls["n"] * B
+    def noise_fn(B):                      # recorded draws, consumed microbatch by microbatch (a later step starts over)
+        a = lo + (calls["n"] * B) % (hi - lo)
         calls["n"] += 1
         return rnd[a:a + B].cuda(), epsn[a:a + B].cuda(), mnoise[a:a + B].cuda()
     model._noise_fn = noise_fn

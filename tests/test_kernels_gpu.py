@@ -504,6 +504,55 @@ def test_gemm_operand_lists(hip):
                     expect=None) == -1
 
 
+@pytest.mark.parametrize("ks", [1, 2, 4])
+def test_gemm_grouped_problems(hip, ks):
+    """md_gemm_args.problems: several weight gradients that contract over the same tokens as ONE pp256 launch (tiles of all
+    problems share the workgroups), fp32 slices laid out like the gradient tensors (a gap between two of them is left alone),
+    one md_splitk_reduce_flat per contiguous run.  Shapes: qkv / proj / q_linear-like plus ragged ones (rows not a multiple of
+    256, columns only a multiple of 8)."""
+    import ctypes
+    torch.manual_seed(11 + ks)
+    L, st = hip.lib(), hip.stream_ptr()
+    T = 1024                                               # tokens (the shared contraction)
+    shapes = [(1920, 1024), (1024, 640), (1024, 1024), (200, 72), (520, 264)]          # (out rows = N_lin, out cols = K_lin)
+    gap_after = 1                                          # a foreign tensor (kv_linear in a real block) between problems 1 and 2
+    sizes = [m * n for m, n in shapes]
+    offs, o = [], 0
+    for i, sz in enumerate(sizes):
+        offs.append(o)
+        o += (sz + 63) // 64 * 64
+        if i == gap_after:
+            o += 4096
+    span = o
+    G = torch.full((span,), 0.5, device=DEV)               # the "gradient accumulators": reduced into with accumulate = 1
+    dys = [bf(torch.randn(T, m, device=DEV)) for m, _ in shapes]
+    xs = [bf(torch.randn(T, n, device=DEV) / math.sqrt(T)) for _, n in shapes]
+    probs = (hip.GemmProblem * len(shapes))()
+    for i, (m, n) in enumerate(shapes):
+        probs[i] = hip.GemmProblem(dys[i].data_ptr(), xs[i].data_ptr(), m, n, m, n, offs[i])
+    ws = torch.full((ks, span), float("nan"), device=DEV)
+    a = hip.GemmArgs()
+    for k, v in dict(A=dys[0].data_ptr(), B=xs[0].data_ptr(), C=ws.data_ptr(), M=shapes[0][0], N=shapes[0][1], K=T, lda=shapes[0][0],
+                     ldb=shapes[0][1], ldc=shapes[0][1], sSplit=span, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
+                     mode=hip.EPI_STORE_F32, act=0, alpha=1.0, problems=ctypes.addressof(probs), n_problems=len(shapes)).items():
+        setattr(a, k, v)
+    hip.check(L.md_gemm_bf16(ctypes.byref(a), st), "grouped gemm")
+    runs = [(offs[0], offs[1] + sizes[1]), (offs[2], offs[4] + sizes[4])]
+    for lo, hi in runs:
+        n = ((hi - lo) + 3) // 4 * 4
+        hip.check(L.md_splitk_reduce_flat(ws.data_ptr() + 4 * lo, G.data_ptr() + 4 * lo, n, span, ks, 1, st), "flat reduce")
+    torch.cuda.synchronize()
+    for i, (m, n) in enumerate(shapes):
+        ref = 0.5 + dys[i].float().t() @ xs[i].float()
+        close(G[offs[i]:offs[i] + m * n].view(m, n), ref, rel=2e-3, what=f"grouped problem {i} {m}x{n}, ksplit {ks}")
+    gap = G[offs[1] + sizes[1]:offs[2]]
+    pad_end = (sizes[1] + 63) // 64 * 64 - sizes[1]
+    assert torch.all(gap[pad_end:] == 0.5), "the gap between two runs must not be touched"
+    # a grouped launch on anything but the K-strided x K-strided fp32-slice kernel is a bad argument
+    a.a_kcontig = 1
+    assert L.md_gemm_bf16(ctypes.byref(a), st) == -1
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_adamw_clip(hip):
     """clip_grad_norm_ + torch.optim.AdamW (train.py:39-43,85-86) vs md_sumsq / md_sumsq_finish / md_adamw_step, with the

@@ -274,7 +274,9 @@ def test_grouped_deferred_dgrads_equal_per_layer(hip):
     """The condition-vector gradients of all adaLN layers of a group (ONE operand-list launch, md_gemm_args.A_list / B_list,
     one slice per layer part) and the caption-token gradients of all cross-attention kv projections of a group (ONE launch over
     the K-concatenation of the blocks' operands, list_segments) must give the gradients of the layer-by-layer form: everything
-    upstream of dgc / dy (timestep embedder, pooled-caption MLP, caption block, caption projection) sees them."""
+    upstream of dgc / dy (timestep embedder, pooled-caption MLP, caption block, caption projection) sees them.  The same switch
+    covers the grouped weight-gradient launches (md_gemm_args.problems: w3, [w1; w2], cross_attn.proj, q_linear as one launch,
+    attn.proj + attn.qkv as another)."""
     cfg = orc.tiny_config()
     sd = orc.dezero_state_dict(orc.synth_state_dict(cfg, 33))
     batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 34)
@@ -283,7 +285,7 @@ def test_grouped_deferred_dgrads_equal_per_layer(hip):
     gs = {}
     for grouped in (True, False):
         m = _product(cfg, sd)
-        m.dit.engine.group_adaln = m.dit.engine.group_dycond = grouped
+        m.dit.engine.group_adaln = m.dit.engine.group_dycond = m.dit.engine.group_wgrad = grouped
         m.dit.engine.gemm_log = []
         m._noise_fn = lambda b: noise
         m.train_microbatch(gb)
@@ -311,9 +313,11 @@ def test_ema_weights_are_the_ones_evaluated(hip):
     torch.manual_seed(0)
     _steps(model, tr, cfg, 1, 4, 400)
     p_after1 = model.dit.flat_buffers()["p"].clone()
+    model._noise_fn = None                                                   # evaluation draws its own noise (seeded below)
     torch.manual_seed(1)
     base = train_py.evaluate(model, ev, 1, microbatch=3, opt=None)           # raw weights after step 1 == the EMA
     _steps(model, tr, cfg, 3, 4, 401)
+    model._noise_fn = None
     p_now = model.dit.flat_buffers()["p"].clone()
     assert not torch.equal(p_now, p_after1)
     assert torch.equal(opt.ema, p_after1)
