@@ -52,21 +52,21 @@ class _Arena:
         self.measuring = True
 
     def begin(self, key):
+        """Start a pass of shape `key`.  The buffer is (re)allocated HERE, never at the end of a measuring pass: the tensors of
+        the measuring pass (a whole activation tape: 156 GB for XL/2 at microbatch 1024) are still alive when it ends, and
+        measured peak + buffer would not fit the HBM; by the next pass the caller has dropped them."""
         self.key = key
         need = self.peaks.get(key)
-        self.measuring = need is None or self.buf is None or self.buf.numel() < need + self.ALIGN
+        if need is not None and (self.buf is None or self.buf.numel() < need + self.ALIGN):
+            want = max(self.peaks.values()) + self.ALIGN
+            self.buf = None             # release before re-allocating
+            self.buf = torch.empty(want, device=self.dev, dtype=torch.uint8)
+        self.measuring = need is None
         self.top = self.peak = 0
 
     def end(self, ok: bool = True):
-        if not self.measuring:
-            return
-        if not ok:                      # the pass raised half-way: its peak is not the shape's peak
-            return
-        self.peaks[self.key] = self.peak
-        need = max(self.peaks.values()) + self.ALIGN
-        if self.buf is None or self.buf.numel() < need:
-            self.buf = None             # release before re-allocating
-            self.buf = torch.empty(need, device=self.dev, dtype=torch.uint8)
+        if self.measuring and ok:       # a pass that raised half-way did not reach the shape's peak: not recorded
+            self.peaks[self.key] = self.peak
 
     def mark(self) -> int:
         return self.top
@@ -125,6 +125,7 @@ class DiTEngine:
         self._ptr_cache = {}
         self.ksplit_min_items = 192  # work items a split-K factor must reach (A/B: 128 = the round-2 rule)
         self.splitk_force_pp = False  # A/B: force pp256 for every split-K launch it accepts, whatever the tile count
+        self.short_k_accum = True   # A/B: False = split-K slices also for short contractions into large outputs
         self.group_wgrad = True     # the weight gradients of a block that contract over the same tokens as grouped launches (A/B: False)
         self._wgroup = None
         self.single_slice_ws = True  # launches with >= 192 tiles of their own: one fp32 slice through the workspace on pp256 (A/B: False = accumulate epilogue)
@@ -245,6 +246,9 @@ class DiTEngine:
         tiny outputs) the round-1 rule for the 2-stage kernels: ~3 workgroups of 128 x 128 per CU, >= 512 k per split."""
         ws_cap = max(1, self.ws.numel() // (out_rows * out_cols * batch))
         t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256) * batch
+        if getattr(self, "short_k_accum", True) and contraction <= 512 and t256 >= 64:
+            return 1        # a short contraction into a large output (the adaLN weight gradients: 256 tokens into 6144 x 1024) is
+            #                 pure output traffic: accumulate in place (one read + one write) instead of slices + a reduction pass
         if contraction % 128 == 0 and out_cols % 8 == 0:
             units = contraction // 128
             out_us = out_rows * out_cols * batch * 4 / 4e6

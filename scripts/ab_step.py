@@ -40,6 +40,7 @@ def main():
                 setattr(eng, k, type(getattr(eng, k))(int(val)))
             for ar in (eng._tape_arena, eng._scratch_arena):     # the launch sequence may change with the options: re-measure
                 ar.peaks.clear()
+                ar.buf = None
             e, loss = st.timed(a.steps, 1, 1)
             res.setdefault(name, []).append(2048 * a.steps / e)
             print(f"{name:24s} round {rnd}: {2048 * a.steps / e:8.1f} img/s  loss {loss:.5f}", flush=True)

@@ -221,6 +221,27 @@ def test_xl2_train_step_parity(hip, tag, prefer):
     F_hip = eng.sample_image(eng.last_tape).float().cpu()
     F_rep = {"rel_rms": _rel_rms(F_hip, o["taps"]["F"]), "gain": _gain(F_hip, o["taps"]["F"]),
              "per_sample_gain": [_gain(F_hip[i], o["taps"]["F"][i]) for i in range(F_hip.shape[0])]}
+    # the final layer (utils.py:236-240) op by op against the oracle's own intermediates: shift / scale = adaLN(gelu(c)),
+    # modulated LayerNorm of the last residual stream, the p*p*C projection (kept tokens, before unmask / unpatchify)
+    tp, tap, sdf = eng.last_tape, o["taps"], {k: v.float() for k, v in sd.items() if k.startswith("final_layer.")}
+    D = cfg.dim
+    gco = torch.nn.functional.gelu(tap["c"], approximate="tanh")
+    fmod_o = gco @ sdf["final_layer.adaLN_modulation.1.weight"].t() + sdf["final_layer.adaLN_modulation.1.bias"]
+    hb = tap["backbone_out"]
+    xf_o = torch.nn.functional.layer_norm(hb, (D,), sdf["final_layer.norm_final.weight"], None, cfg.norm_eps)
+    xf_o = xf_o * (1 + fmod_o[:, D:].unsqueeze(1)) + fmod_o[:, :D].unsqueeze(1)
+    tok_o = xf_o @ sdf["final_layer.linear.weight"].t() + sdf["final_layer.linear.bias"]
+    fm_h = tp.fmod.float().cpu()
+    F_rep["final_layer"] = {
+        "c": {"gain": _gain(tp.c.float().cpu(), tap["c"]), "rel_rms": _rel_rms(tp.c.float().cpu(), tap["c"])},
+        "shift": {"gain": _gain(fm_h[:, :D], fmod_o[:, :D]), "rel_rms": _rel_rms(fm_h[:, :D], fmod_o[:, :D])},
+        "scale": {"gain": _gain(fm_h[:, D:], fmod_o[:, D:]), "rel_rms": _rel_rms(fm_h[:, D:], fmod_o[:, D:])},
+        "modulated_ln": {"gain": _gain(tp.xf.float().cpu().view(-1), xf_o.reshape(-1)), "rel_rms": _rel_rms(tp.xf.float().cpu().view(-1), xf_o.reshape(-1))},
+        "tokens": {"gain": _gain(tp.out_tok.float().cpu().view(-1), tok_o.reshape(-1)), "rel_rms": _rel_rms(tp.out_tok.float().cpu().view(-1), tok_o.reshape(-1))},
+        "tokens_from_oracle_xf_bf16_weights": {"gain": _gain((xf_o.bfloat16().float() @ sdf["final_layer.linear.weight"].bfloat16().float().t()
+                                                                + sdf["final_layer.linear.bias"]).reshape(-1), tok_o.reshape(-1))},
+        "rms": {"backbone_out": float(hb.pow(2).mean().sqrt()), "scale": float(fmod_o[:, D:].pow(2).mean().sqrt()),
+                "shift": float(fmod_o[:, :D].pow(2).mean().sqrt()), "tokens": float(tok_o.pow(2).mean().sqrt())}}
     eng.route_override = None
     mixer_keys = [k for k in drift if k.startswith("patch_mixer")]
     every4 = mixer_keys[-1:] + [k for k in drift if k.startswith("blocks.") and int(k.split(".")[1]) % 4 == 3]
