@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MD_ABI_VERSION 2
+#define MD_ABI_VERSION 3
 int md_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM */

@@ -1,5 +1,5 @@
-"""Turn the two rocprofv3 --pmc passes of scripts/pmc_workload.py into profiles/r2_gemm_traffic.json (bench.py reads it for
-roofline.traffic).  FETCH_SIZE / WRITE_SIZE are calibrated on the known-size copy launches of the same run (the guide's
+"""Turn the two rocprofv3 --pmc passes of scripts/pmc_workload.py into profiles/r3_gemm_traffic.json (bench.py reads it for
+roofline.traffic and compares the `library_source_hash` stamped here with the build it runs: a stale file yields traffic null).  FETCH_SIZE / WRITE_SIZE are calibrated on the known-size copy launches of the same run (the guide's
 gfx950 note: FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads; WRITE_SIZE is uncalibrated): the factor
 that maps the counter to 2^30 bytes on the copy kernel is applied to the GEMM launches.
     python scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [out.json]"""
@@ -32,7 +32,7 @@ def load(d, counter):
 
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
-    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r2_gemm_traffic.json")
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3_gemm_traffic.json")
     fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 
     def copy_kernel(per):
@@ -47,7 +47,9 @@ def main():
     n = sum(len(v) for v in gem_f.values())
     fb = sum(sum(v) for v in gem_f.values()) * f_cal
     wb = sum(sum(v) for v in gem_w.values()) * w_cal
-    res = {"bytes_per_launch": (fb + wb) / n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "launches": n,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from micro_diffusion_amd import hip
+    res = {"library_source_hash": hip._source_hash(), "bytes_per_launch": (fb + wb) / n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "launches": n,
            "calibration": {"fetch_counter_to_bytes": f_cal, "write_counter_to_bytes": w_cal, "on": fk[:60],
                            "note": "factor that maps the counter to 2^30 bytes on a torch copy of 1 GiB in the same run"},
            "per_kernel": {k[:70]: {"launches": len(v), "fetch_bytes_per_launch": sum(v) * f_cal / len(v),

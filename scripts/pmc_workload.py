@@ -3,7 +3,7 @@ elementwise copy, 16-byte accesses: 1 GiB read + 1 GiB written per launch) follo
 MicroDiT-XL/2 microbatch (the GEMM launches of the headline step).  Run once per counter:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python scripts/pmc_workload.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python scripts/pmc_workload.py
-then scripts/pmc_traffic.py turns the two CSVs into profiles/r2_gemm_traffic.json."""
+then scripts/pmc_traffic.py turns the two CSVs into profiles/r3_gemm_traffic.json (stamped with the library's source hash)."""
 import os
 import sys
 
@@ -28,6 +28,6 @@ g = torch.Generator(device="cuda").manual_seed(1)
 batch = {"image_latents": (torch.randn(mb, 4, 32, 32, device="cuda", generator=g) * 0.8).half(),
          "caption_latents": torch.randn(mb, 1, 77, 1024, device="cuda", generator=g).half(),
          "drop_caption_mask": torch.ones(mb, device="cuda")}
-model(batch)[0].backward()
+model.train_microbatch(batch)           # the Trainer's autograd-free microbatch: the launch sequence bench.py times
 torch.cuda.synchronize()
 print("pmc workload done")

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.md_abi_version() == 2
+    assert lib.md_abi_version() == 3
 
 
 def test_product_never_imports_oracle():

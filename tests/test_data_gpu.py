@@ -1,6 +1,8 @@
 """Latents data path on the GPU: prefetching loader (pinned staging, copy stream, event ordering) delivers exactly the
 bytes the CPU restatement reads, while the consumer overwrites / reads the batches on its own stream; and a training
 step consumes loader batches directly."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -98,3 +100,54 @@ def test_train_py_eval_loop_and_ema(shards, tmp_path, capsys):
     rel = float((opt.ema - p).norm() / p.norm())
     assert 0 < rel < 1e-2, rel
     assert tr.model.training
+
+
+def test_train_py_autoresume_and_stage_handoff(tmp_path, capsys):
+    """train.py checkpoints (weights under Composer's `state/model/dit.*` keys, AdamW moments keyed by parameter name, batch counter,
+    loader position), `trainer.autoresume` continues the run, and a later stage picks the checkpoint up through `load_path`
+    (configs/res_256_finetune.yaml:92-97: optimizer moments carried, the stage's own learning rate) -- f-3 of SURVEY.md section 8."""
+    import json
+    import train as train_mod
+    target = "micro_diffusion.datasets.latents_loader.build_streaming_latents_dataloader"
+    folder = os.path.join(tmp_path, "run")
+
+    def cfg(max_ba, **trainer):
+        return {
+            "seed": 18,
+            "model": {"_target_": "micro_diffusion.models.model.create_latent_diffusion", "dit_arch": "MicroDiT_Tiny_2", "latent_res": 32,
+                      "in_channels": 4, "pos_interp_scale": 1.0, "dtype": "bfloat16", "precomputed_latents": True, "p_mean": -0.6,
+                      "p_std": 1.2, "train_mask_ratio": 0.75, "vae_name": "x", "text_encoder_name": "openclip:hf-hub:apple/DFN5B-CLIP-ViT-H-14-378"},
+            "optimizer": {"_target_": "torch.optim.AdamW", "lr": 1e-4, "weight_decay": 0.1, "eps": 1e-8, "betas": [0.9, 0.999]},
+            "scheduler": {"_target_": "composer.optim.ConstantScheduler", "alpha": 1.0},
+            "algorithms": {"gradient_clipping": {"clip_norm": 0.25, "clipping_type": "norm"}},
+            "dataset": {"image_size": 256, "train_batch_size": 8, "eval_batch_size": 8, "cap_drop_prob": 0.1,
+                        "train": {"_target_": target, "datadir": "synthetic"}},
+            "trainer": dict({"max_duration": f"{max_ba}ba", "device_train_microbatch_size": 4, "save_interval": "2ba", "save_folder": folder}, **trainer),
+            "misc": {"log_interval": 1},
+        }
+    tr = train_mod.train(cfg(2))
+    ck = torch.load(os.path.join(folder, "latest.pt"), map_location="cpu")
+    assert ck["batch"] == 2 and ck["optimizer"]["format"] == "by_name" and ck["optimizer"]["step"] == 2
+    names = {k for k, _ in tr.model.dit.named_parameters()}
+    assert set(ck["optimizer"]["m"]) == names and {k[len("dit."):] for k in ck["state"]["model"]} >= names
+    m_saved = {k: v.clone() for k, v in ck["optimizer"]["m"].items()}
+    capsys.readouterr()
+    # ---- autoresume: two more batches on top of the two that were saved
+    tr2 = train_mod.train(cfg(4, autoresume=True))
+    out = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert any(l.get("resumed_from") for l in out) and tr2.batches_seen == 4 and tr2.opt.step_count == 4
+    assert [l["batch"] for l in out if "loss" in l] == [3, 4]
+    # ---- next stage: weights + moments from the checkpoint of batch 2 (saved above under a different name), its own lr
+    torch.save(ck, os.path.join(tmp_path, "stage1.pt"))
+    c3 = cfg(1, load_path=os.path.join(tmp_path, "stage1.pt"), load_ignore_keys=["state/model/dit.pos_embed"])
+    c3["trainer"]["save_folder"] = os.path.join(tmp_path, "run2")
+    c3["trainer"]["save_interval"] = "0ba"
+    c3["optimizer"]["lr"] = 3e-5
+    tr3 = train_mod.train(c3)
+    assert tr3.opt.step_count == 3 and tr3.opt.lr == 3e-5          # moments carried: the step counter continues from 2
+    k = "blocks.0.attn.qkv.weight"
+    b1 = 0.9
+    after = tr3.opt.state_dict()["m"][k].cpu()
+    # m_3 = b1 * m_2 + (1 - b1) * g_3: the carried moment is still most of it
+    cos = float((after * m_saved[k]).sum() / (after.norm() * m_saved[k].norm()))
+    assert cos > 0.8, cos

@@ -238,6 +238,12 @@ def test_xl2_train_step_parity(hip, tag, prefer):
         "scale": {"gain": _gain(fm_h[:, D:], fmod_o[:, D:]), "rel_rms": _rel_rms(fm_h[:, D:], fmod_o[:, D:])},
         "modulated_ln": {"gain": _gain(tp.xf.float().cpu().view(-1), xf_o.reshape(-1)), "rel_rms": _rel_rms(tp.xf.float().cpu().view(-1), xf_o.reshape(-1))},
         "tokens": {"gain": _gain(tp.out_tok.float().cpu().view(-1), tok_o.reshape(-1)), "rel_rms": _rel_rms(tp.out_tok.float().cpu().view(-1), tok_o.reshape(-1))},
+        # the same projected error split into its token-constant part (per-sample mean over the kept tokens: shift / bias path and
+        # the mean residual error, 16 numbers per sample -> few degrees of freedom) and the token-varying rest
+        "tokens_token_mean_part": {"gain": _gain(tp.out_tok.float().cpu().view(tok_o.shape).mean(1), tok_o.mean(1)),
+                                   "share_of_signal_power": float(tok_o.mean(1, keepdim=True).expand_as(tok_o).pow(2).sum() / tok_o.pow(2).sum())},
+        "tokens_centered_part": {"gain": _gain(tp.out_tok.float().cpu().view(tok_o.shape) - tp.out_tok.float().cpu().view(tok_o.shape).mean(1, keepdim=True),
+                                               tok_o - tok_o.mean(1, keepdim=True))},
         "tokens_from_oracle_xf_bf16_weights": {"gain": _gain((xf_o.bfloat16().float() @ sdf["final_layer.linear.weight"].bfloat16().float().t()
                                                                 + sdf["final_layer.linear.bias"]).reshape(-1), tok_o.reshape(-1))},
         "rms": {"backbone_out": float(hb.pow(2).mean().sqrt()), "scale": float(fmod_o[:, D:].pow(2).mean().sqrt()),
