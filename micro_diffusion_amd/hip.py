@@ -119,6 +119,7 @@ class GemmArgs(Structure):
 
 
 _lib = None
+ABI_VERSION = 3        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
 
 
 def lib() -> ctypes.CDLL:
@@ -142,8 +143,9 @@ def lib() -> ctypes.CDLL:
                 "There is no CPU / PyTorch fallback for the training path.")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.md_abi_version() != 2:
-            raise RuntimeError("libmicrodit_hip.so ABI version mismatch; rebuild")
+        if _lib.md_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libmicrodit_hip.so reports ABI version {_lib.md_abi_version()}, this binding is written for "
+                               f"{ABI_VERSION}; rebuild")
     return _lib
 
 
