@@ -175,6 +175,12 @@ class Stage:
         return elapsed, float(loss.item())
 
     def close(self):
+        eng = self.model.dit.engine
+        eng._tape_arena.buf = eng._scratch_arena.buf = None      # the activation arenas (156 GB at microbatch 1024) go first,
+        eng._tape_arena.peaks.clear()                            # whoever else still holds the engine
+        eng._scratch_arena.peaks.clear()
+        eng.ws = None
+        eng = None
         self.model = self.trainer = self.batch = None
         gc.collect()
         torch.cuda.empty_cache()
@@ -320,6 +326,7 @@ def main():
                             "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS,
                             "share_of_step": (ms / ms_per_step) if world == 1 else None}
         eng.kernel_profile = None
+        eng = None
         out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_TBS, "unit": "TB/s", "kernels": dict(sorted(hb.items(), key=lambda kv: -kv[1]["total_ms"]))}
     if world == 1 and not args.no_other_stages:
         # ---- the YAML microbatch (the per-rank shape of an 8-GPU run) on the same model

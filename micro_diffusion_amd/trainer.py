@@ -493,6 +493,8 @@ class Trainer:
         self.microbatch_size = microbatch_size
         if dp_mode == "auto" and os.environ.get("MD_DP_MODE"):
             dp_mode = os.environ["MD_DP_MODE"]
+        if exchange == "auto" and os.environ.get("MD_DP_EXCHANGE"):
+            exchange = os.environ["MD_DP_EXCHANGE"]
         model.dit._ensure_flat()
         self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange, mode=dp_mode)
         self.sync.norm_partials = optimizer.partials

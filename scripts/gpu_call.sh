@@ -12,6 +12,7 @@
 #   ab[:<args>]                python scripts/ab_step.py <args> (same-process A/B of engine options)
 #   traffic                    the two PMC passes of scripts/pmc_workload.py + scripts/pmc_traffic.py -> gpurun_out/<tag>_gemm_traffic.json
 #   py:<script and args>       python <script and args>
+#   dp2gloo[:<bench flags>]    bench.py --gpus 2, both ranks on this GPU over gloo (functional run of the N > 1 path)
 # Colons separate the step name from its argument; spaces inside an argument must be written as '+'.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -52,6 +53,12 @@ for step in "$@"; do
       find "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" -type f -size +1M -delete 2>/dev/null ;;
     py)
       timeout -k 10 900 python $arg > "$log" 2>&1; tail -n 40 "$log" ;;
+    dp2gloo)
+      # bench.py --gpus 2 with BOTH ranks on this one GPU over gloo (host-bounced collectives): a functional run of the N > 1
+      # bench path (dp block of the JSON line, sharded optimiser step), not a measurement
+      MD_DIST_BACKEND=gloo MD_DP_MODE=${MD_DP_MODE:-sharded} MD_DP_EXCHANGE=bf16 timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --microbatch 256 --no-cpu-baseline --no-other-stages $arg > "$log" 2>&1
+      grep "^{" "$log" | tail -n 1 > gpurun_out/${tag}_bench_dp2_gloo.json; cut -c1-600 gpurun_out/${tag}_bench_dp2_gloo.json; tail -n 5 "$log" | cut -c1-300 ;;
     *) echo "unknown step $name" ;;
   esac
 done
