@@ -187,14 +187,20 @@ class Stage:
 
 
 def gemm_traffic():
-    """HBM bytes per GEMM launch of the headline step from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 and
-    WRITE_SIZE in separate --pmc runs of this command; scripts/pmc_traffic.py writes the file)."""
-    path = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+    """HBM bytes per GEMM launch of the headline step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate --pmc runs, calibrated on a 1 GiB copy of the same pass; scripts/pmc_workload.py + scripts/pmc_traffic.py write the
+    file).  The counters need rocprofv3 around the process, so they are NOT measured by this run; the number is returned only
+    when the file was measured on THIS build of the library (source hash stamped into it), else null + `stale`."""
+    from micro_diffusion_amd import hip
+    path = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, {"file": None, "traffic_measured_in_run": False}
     with open(path) as fh:
         t = json.load(fh)
-    return t.get("bytes_per_launch"), t
+    info = {k: v for k, v in t.items() if k != "per_kernel"}
+    info.update(file="profiles/r3_gemm_traffic.json", traffic_measured_in_run=False, running_build=hip._source_hash(),
+                stale=t.get("library_source_hash") != hip._source_hash())
+    return (None if info["stale"] else t.get("bytes_per_launch")), info
 
 
 def main():
