@@ -61,4 +61,5 @@ if spans:
         if s > cur:
             idle += s - cur
         cur = max(cur, e)
-    print(f"# span {span / 1e6:.1f} ms, idle between kernels {idle / 1e6:.1f} ms ({100 * idle / span:.1f} %)")
+    print(f"# first to last kernel of the process {span / 1e6:.1f} ms, of which no kernel running {idle / 1e6:.1f} ms (includes model build and "
+          f"host-side set-up between the legs: not a measure of launch gaps inside a step)")
