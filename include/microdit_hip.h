@@ -295,6 +295,13 @@ typedef struct md_adamw_args {
     int32_t ema_mode;    /* 0 = none, 1 = ema <- updated weights (ema_start), 2 = ema <- s * ema + (1 - s) * weights */
 } md_adamw_args;
 int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
+/* The sharded form of the same pass (FSDP SHARD_GRAD_OP, configs/res_256_pretrain.yaml:117-118: every rank updates its slice of
+ * the optimiser state): ONE launch over n_ranges <= MD_ADAMW_MAX_RANGES chunks of the flat buffers.  Range j covers flat
+ * elements [flat_off[j], flat_off[j] + count[j]) of p / m / v / ema (a->p ... are the flat bases); a->g_bf16 (the
+ * reduce-scattered gradient) and a->shadow (the bf16 weights to all-gather) are PACKED: range j starts at sum(count[0..j)).
+ * a->n is ignored; zero_grad must be 0 (the staging cast cleared the accumulators).  flat_off / count are HOST arrays. */
+#define MD_ADAMW_MAX_RANGES 64
+int md_adamw_step_ranges(const md_adamw_args* a, const int64_t* flat_off, const int64_t* count, int32_t n_ranges, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------- probes (tests only) */
 int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);

@@ -61,8 +61,17 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* partial,
     if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <bool GBF16, int EMA>
-__global__ __launch_bounds__(256) void adamw_kernel(md_adamw_args a) {
+// Range table of the sharded optimiser step (md_adamw_step_ranges): the rank's chunks of the flat buffers, packed back to back in
+// the index space the kernel walks.  Packed element i of range j lives at flat element flat[j] + (i - start[j]).
+constexpr int ADAMW_MAX_RANGES = MD_ADAMW_MAX_RANGES;
+struct AdamWRanges {
+    int n;
+    int64_t start[ADAMW_MAX_RANGES + 1];     // start[n] = total packed elements
+    int64_t flat[ADAMW_MAX_RANGES];
+};
+
+template <bool GBF16, int EMA, bool RANGES>
+__global__ __launch_bounds__(256) void adamw_kernel(md_adamw_args a, AdamWRanges rg) {
     float coef = a.grad_scale;
     if (a.sumsq && a.max_norm > 0.f) {
         const float nrm = sqrtf(*reinterpret_cast<const float*>(a.sumsq)) * a.grad_scale;
@@ -82,13 +91,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(md_adamw_args a) {
     const int64_t n4 = a.n / 4;
     // Every stream is touched exactly once: non-temporal loads / stores keep 40 GB of one-shot traffic from rotating through
     // the L2s and the Infinity Cache.
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t ip = (int64_t)blockIdx.x * 256 + threadIdx.x; ip < n4; ip += (int64_t)gridDim.x * 256) {
+        // RANGES: ip indexes the PACKED space (where the bf16 gradient and the bf16 weight output live); i is the same float4 in
+        // the flat buffers (masters, moments, EMA, fp32 gradient).  Chunks are multiples of 64 elements: a float4 never straddles.
+        int64_t i = ip;
+        if (RANGES) {
+            int lo = 0, hi = rg.n - 1;
+            const int64_t e = ip * 4;
+            while (lo < hi) {                      // last range whose start <= e
+                const int mid = (lo + hi + 1) >> 1;
+                if (rg.start[mid] <= e) lo = mid; else hi = mid - 1;
+            }
+            i = (rg.flat[lo] + (e - rg.start[lo])) >> 2;
+        }
         float4 p = nt_load4(P + i * 4);
         float4 m = nt_load4(Mo + i * 4);
         float4 v = nt_load4(Vo + i * 4);
         float4 g;
         if (GBF16) {
-            const bf16x4 gb = ld_bf16x4(Gb + i * 4);
+            const bf16x4 gb = ld_bf16x4(Gb + ip * 4);
             g = make_float4(bf2f(gb[0]), bf2f(gb[1]), bf2f(gb[2]), bf2f(gb[3]));
         } else {
             g = nt_load4(G + i * 4);
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(md_adamw_args a) {
         if (S) {
             bf16x4 o;
             o[0] = f2bf(p.x); o[1] = f2bf(p.y); o[2] = f2bf(p.z); o[3] = f2bf(p.w);
-            st_bf16x4(S + i * 4, o);          // re-read by every GEMM of the next step: left cacheable
+            st_bf16x4(S + ip * 4, o);         // re-read by every GEMM of the next step: left cacheable
         }
     }
 }
@@ -147,13 +168,42 @@ extern "C" int md_adamw_step(const md_adamw_args* a, hipStream_t st) {
     int64_t grid = (a->n / 4 + 255) / 256;
     if (grid > 8192) grid = 8192;
     const dim3 gd((unsigned)grid), bd(256);
-#define ADAMW(GB, E) hipLaunchKernelGGL((adamw_kernel<GB, E>), gd, bd, 0, st, *a)
+    AdamWRanges none;
+    none.n = 0;
+#define ADAMW(GB, E) hipLaunchKernelGGL((adamw_kernel<GB, E, false>), gd, bd, 0, st, *a, none)
     if (a->g_bf16) {
         if (a->ema_mode == 0) ADAMW(true, 0); else if (a->ema_mode == 1) ADAMW(true, 1); else ADAMW(true, 2);
     } else {
         if (a->ema_mode == 0) ADAMW(false, 0); else if (a->ema_mode == 1) ADAMW(false, 1); else ADAMW(false, 2);
     }
 #undef ADAMW
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_adamw_step_ranges(const md_adamw_args* a, const int64_t* flat_off, const int64_t* count, int32_t n_ranges,
+                                    hipStream_t st) {
+    if (!a || !a->p || !a->g || !a->m || !a->v || !a->g_bf16 || !flat_off || !count || n_ranges < 1 || n_ranges > ADAMW_MAX_RANGES)
+        return MD_BAD_ARG;
+    if (a->ema_mode < 0 || a->ema_mode > 2 || (a->ema_mode && !a->ema) || a->zero_grad) return MD_BAD_ARG;
+    AdamWRanges rg;
+    rg.n = n_ranges;
+    int64_t tot = 0;
+    for (int j = 0; j < n_ranges; ++j) {
+        if (count[j] <= 0 || count[j] % 4 || flat_off[j] < 0 || flat_off[j] % 4) return MD_BAD_ARG;
+        rg.start[j] = tot;
+        rg.flat[j] = flat_off[j];
+        tot += count[j];
+    }
+    rg.start[n_ranges] = tot;
+    md_adamw_args b = *a;
+    b.n = tot;                                   // the kernel walks the packed space
+    int64_t grid = (tot / 4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    const dim3 gd((unsigned)grid), bd(256);
+#define ADAMWR(E) hipLaunchKernelGGL((adamw_kernel<true, E, true>), gd, bd, 0, st, b, rg)
+    if (a->ema_mode == 0) ADAMWR(0); else if (a->ema_mode == 1) ADAMWR(1); else ADAMWR(2);
+#undef ADAMWR
     MD_LAUNCH_CHECK();
     return 0;
 }

@@ -148,12 +148,28 @@ class FusedAdamW:
         if max_norm and max_norm > 0:
             sync.finish_sharded_norm(norm_slots, self.sumsq)
             ss = self.sumsq.data_ptr()
-        for key, lo, hi, chunk, olo in sync.plan:
-            n = chunk if chunk_of is None else (hi - lo) // chunk_of // 64 * 64
-            if n <= 0:
-                continue
-            self._launch(lo + sync.rank * chunk, n, lr, max_norm, grad_scale, ss, sync.gred.data_ptr() + 2 * olo,
-                         sync.ssend.data_ptr() + 2 * olo, 0, ema_mode)
+        # ONE launch over the rank's chunks (md_adamw_step_ranges: the kernel walks the packed space the reduce-scattered gradient
+        # and the send buffer live in, a range table maps it onto the flat masters / moments)
+        ranges = [(lo + sync.rank * chunk, chunk if chunk_of is None else (hi - lo) // chunk_of // 64 * 64) for _, lo, hi, chunk, _ in sync.plan]
+        ranges = [r for r in ranges if r[1] > 0]
+        if len(ranges) <= 64:        # (with chunk_of the packed gradient / weight offsets no longer line up: timing only, as documented)
+            import ctypes
+            key = tuple(ranges)
+            if getattr(self, "_range_key", None) != key:
+                self._range_key = key
+                self._range_off = (ctypes.c_int64 * len(ranges))(*[r[0] for r in ranges])
+                self._range_cnt = (ctypes.c_int64 * len(ranges))(*[r[1] for r in ranges])
+            b1, b2 = self.betas
+            a = hip.AdamWArgs(f["p"].data_ptr(), f["g"].data_ptr(), self.m.data_ptr(), self.v.data_ptr(), sync.ssend.data_ptr(), ss,
+                              sync.gred.data_ptr(), self.ema.data_ptr() if self.ema is not None else None, 0, lr, b1, b2, self.eps,
+                              self.weight_decay, 1 - b1 ** self.step_count, 1 - b2 ** self.step_count, max_norm or 0.0, grad_scale,
+                              self.ema_smoothing or 0.0, 0, ema_mode)
+            hip.check(hip.lib().md_adamw_step_ranges(byref(a), self._range_off, self._range_cnt, len(ranges),
+                                                     torch.cuda.current_stream().cuda_stream), "md_adamw_step_ranges")
+        else:                                   # more buckets than the kernel's table holds: chunk by chunk
+            for _, lo, hi, chunk, olo in sync.plan:
+                self._launch(lo + sync.rank * chunk, chunk, lr, max_norm, grad_scale, ss, sync.gred.data_ptr() + 2 * olo,
+                             sync.ssend.data_ptr() + 2 * olo, 0, ema_mode)
         if sync.small is not None:
             lo, hi = sync.small
             self._launch(lo, hi - lo, lr, max_norm, grad_scale, ss, sync.gbf.data_ptr() + 2 * lo, f["s"].data_ptr() + 2 * lo, 0, ema_mode)

@@ -663,3 +663,45 @@ def test_moe_layer_with_oracle_routing(hip, variant, B, S, d, f):
     rr = rel_rms(br.cpu().view(B, S, d), ref)
     assert rr <= 0.01, f"MoE layer with injected routing: rel-RMS {rr:.4f} vs fp32 oracle (bf16 storage only: expected ~0.004)"
     close(out, br, rel=1e-2, what="res 0 + gate 1")
+
+
+def test_adamw_step_ranges(hip):
+    """md_adamw_step_ranges (the sharded optimiser step as ONE launch): chunks of the flat buffers named by a range table, the bf16
+    gradient and the bf16 weight output packed back to back -- against md_adamw_step chunk by chunk."""
+    import ctypes
+    torch.manual_seed(12)
+    L, st = hip.lib(), hip.stream_ptr()
+    n = 64 * 700
+    ranges = [(64 * 3, 64 * 10), (64 * 40, 64 * 100), (64 * 300, 64 * 7), (64 * 600, 64 * 100)]
+    packed = sum(c for _, c in ranges)
+    p0, m0, v0 = torch.randn(n, device=DEV), torch.randn(n, device=DEV) * 0.1, torch.rand(n, device=DEV) * 0.01
+    gpk = bf(torch.randn(packed, device=DEV))
+    ss = torch.full((1,), float((gpk.float() ** 2).sum()), device=DEV)
+    res = {}
+    for mode in ("ranges", "chunks"):
+        p, m, v, ema = p0.clone(), m0.clone(), v0.clone(), p0.clone() * 0.5
+        g = torch.zeros(n, device=DEV)
+        spk = torch.zeros(packed, device=DEV, dtype=torch.bfloat16)
+
+        def args(off, cnt, gptr, sptr):
+            return hip.AdamWArgs(p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, sptr, ss.data_ptr(),
+                                 gptr, ema.data_ptr() + 4 * off, cnt, 1e-3, 0.9, 0.999, 1e-8, 0.1, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.25, 0.125, 0.99, 0, 2)
+        if mode == "ranges":
+            off = (ctypes.c_int64 * len(ranges))(*[o for o, _ in ranges])
+            cnt = (ctypes.c_int64 * len(ranges))(*[c for _, c in ranges])
+            a = args(0, 0, gpk.data_ptr(), spk.data_ptr())
+            hip.check(L.md_adamw_step_ranges(ctypes.byref(a), off, cnt, len(ranges), st), "ranges")
+        else:
+            o2 = 0
+            for o, c in ranges:
+                a = args(o, c, gpk.data_ptr() + 2 * o2, spk.data_ptr() + 2 * o2)
+                hip.check(L.md_adamw_step(ctypes.byref(a), st), "chunk")
+                o2 += c
+        torch.cuda.synchronize()
+        res[mode] = (p, m, v, ema, spk)
+    for a_, b_ in zip(res["ranges"], res["chunks"]):
+        assert torch.equal(a_, b_)
+    touched = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for o, c in ranges:
+        touched[o:o + c] = True
+    assert torch.equal(res["ranges"][0][~touched], p0[~touched]) and not torch.equal(res["ranges"][0][touched], p0[touched])
