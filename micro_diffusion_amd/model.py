@@ -107,6 +107,9 @@ class LatentDiffusion(nn.Module):
         return latents, conditioning, drop
 
     def forward(self, batch: dict):
+        """(loss, latents, conditioning) as model.py:104-142.  One deviation: the reference zeroes dropped captions by multiplying
+        the batch's caption tensor in place, so the tensor it returns (and the caller's batch) is modified; here the drop mask is
+        applied inside the first kernel that reads the captions and `conditioning` is returned as it came in."""
         latents, conditioning, drop = self._inputs(batch)
         loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio,
                              _y_rowscale=drop)
