@@ -12,6 +12,7 @@
 #   ab[:<args>]                python scripts/ab_step.py <args> (same-process A/B of engine options)
 #   traffic                    the two PMC passes of scripts/pmc_workload.py + scripts/pmc_traffic.py -> gpurun_out/<tag>_gemm_traffic.json
 #   py:<script and args>       python <script and args>
+#   pmcsq:<M N K akc bkc [mode]>  rocprofv3 SQ counter pass over scripts/pmc_gemm.py for one shape on pp256 (MFMA pipe busy)
 #   dp2gloo[:<bench flags>]    bench.py --gpus 2, both ranks on this GPU over gloo (functional run of the N > 1 path)
 # Colons separate the step name from its argument; spaces inside an argument must be written as '+'.
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -53,6 +54,29 @@ for step in "$@"; do
       find "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" -type f -size +1M -delete 2>/dev/null ;;
     py)
       timeout -k 10 900 python $arg > "$log" 2>&1; tail -n 40 "$log" ;;
+    pmcsq)
+      # SQ counter pass (MFMA pipe busy, wait cycles) over scripts/pmc_gemm.py for ONE shape: arg = "M N K akc bkc [mode]"
+      set -- $arg; shp="$1x$2x$3_$4$5${6:-b}"
+      ( cd /tmp && timeout -k 10 180 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS \
+          SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_${tag}_$shp" -- \
+          python "$GRAFT_REPO_ROOT/scripts/pmc_gemm.py" $1 $2 $3 $4 $5 pp256 ${6:-b} 5 > /dev/null 2>&1 )
+      python - "gpurun_out/pmc_sq_${tag}_$shp" <<'PY' | tee -a gpurun_out/${tag}_pmc_sq_summary.txt
+import collections, csv, glob, sys
+d = sys.argv[1]
+for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'gemm_bf16_pp' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    print('##', d)
+    for k, v in sorted(acc.items()):
+        print(f'  {k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})')
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in acc and 'GRBM_GUI_ACTIVE' in acc:
+        m = sum(acc['SQ_VALU_MFMA_BUSY_CYCLES']) / len(acc['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
+        g = sum(acc['GRBM_GUI_ACTIVE']) / len(acc['GRBM_GUI_ACTIVE']) / 8
+        print(f'  -> MFMA pipe busy {100 * m / g:.1f} % of the kernel; waves waiting {100 * sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]):.1f} %')
+PY
+      find "gpurun_out/pmc_sq_${tag}_$shp" -type f -size +1M -delete 2>/dev/null ;;
     dp2gloo)
       # bench.py --gpus 2 with BOTH ranks on this one GPU over gloo (host-bounced collectives): a functional run of the N > 1
       # bench path (dp block of the JSON line, sharded optimiser step), not a measurement
