@@ -284,7 +284,8 @@ def main():
     if dp is not None:
         sync = head.trainer.sync
         ex = head.trainer.exposed_comm_ms(last=args.steps)
-        dp.update(mode=sync.mode, exchange_dtype=sync.exchange, buckets=sync.last_buckets, bytes_per_step=sync.last_bytes,
+        dp.update(mode=sync.mode, transport=("md_comm (libmicrodit_comm.so over RCCL)" if sync.comm is not None else "torch.distributed"),
+                  exchange_dtype=sync.exchange, buckets=sync.last_buckets, bytes_per_step=sync.last_bytes,
                   optimizer_ms=head.trainer.optimizer_ms(last=args.steps),
                   exposed_comm_ms=ex, exposed_comm_share=(ex / ms_per_step if ex is not None else None),
                   note="exposed_comm_ms = time the compute stream waited for the gradient exchange (and the side-stream bucket "

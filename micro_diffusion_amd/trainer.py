@@ -312,17 +312,24 @@ class GradSync:
     The squared norm of every reduced bucket is taken on a side stream right behind its collective (deterministic partial sums,
     md_sumsq), so the clip coefficient needs no extra pass after the last bucket and is bit-identical on all ranks."""
 
-    def __init__(self, dit, process_group=None, exchange: str = "auto", single_rank_exchange: bool = False, mode: str = "auto"):
+    def __init__(self, dit, process_group=None, exchange: str = "auto", single_rank_exchange: bool = False, mode: str = "auto",
+                 transport: str = "torch"):
         """`single_rank_exchange`: run the whole exchange path (staging cast, asynchronous collectives, side-stream norm) also on
         a process group of ONE rank, where every collective is the identity — the only way to drive the RCCL code path on a box
-        with a single GPU (tests/test_dp_gpu.py); never set in production."""
+        with a single GPU (tests/test_dp_gpu.py); never set in production.
+        `transport`: "torch" — the collectives are torch.distributed calls (backend "nccl" = RCCL); "native" — they go through
+        libmicrodit_comm.so (include/microdit_comm.h: md_comm_*_bucket on the communicator's own high-priority HIP stream), and
+        torch.distributed (any backend) only carries the 128-byte unique id at start-up."""
         self.dit = dit
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.enabled = self.world > 1 or (single_rank_exchange and dist.is_initialized())
+        assert transport in ("torch", "native")
+        self.transport = transport if self.enabled else "torch"
+        self.comm = None
         if exchange == "auto":
-            exchange = "bf16" if (self.enabled and dist.get_backend(process_group) == "nccl") else "fp32"
+            exchange = "bf16" if (self.enabled and (dist.get_backend(process_group) == "nccl" or self.transport == "native")) else "fp32"
         assert exchange in ("bf16", "fp32")
         if mode == "auto":
             mode = "sharded" if (self.enabled and exchange == "bf16") else "allreduce"
@@ -350,7 +357,14 @@ class GradSync:
         dev = f["g"].device
         self.gbf = torch.zeros(f["total"], device=dev, dtype=torch.bfloat16) if (exchange == "bf16" and self.enabled) else None
         self.side = torch.cuda.Stream(device=dev) if (self.enabled and on_gpu) else None
-        self.host_bounce = self.enabled and on_gpu and dist.get_backend(process_group) != "nccl"
+        if self.transport == "native":
+            if not on_gpu:
+                raise ValueError("the native transport moves device buffers over RCCL")
+            from . import comm as mdcomm
+            self.comm = mdcomm.Comm.from_torch_distributed(process_group)
+        # torch.distributed calls on GPU tensors need RCCL underneath; under gloo they bounce through the host
+        self.torch_bounce = self.enabled and on_gpu and dist.get_backend(process_group) != "nccl"
+        self.host_bounce = self.torch_bounce and self.comm is None
         self.plan = self.small = None
         self.gather_work: Dict[str, list] = {}
         if mode == "sharded":
@@ -365,13 +379,16 @@ class GradSync:
         if not self.enabled:
             return "none (single rank)"
         n = len(self.bucket_list)
+        via = " [md_comm over RCCL]" if self.comm is not None else ""
         if self.mode == "sharded":
             return (f"bf16 reduce-scatter per backward segment ({n} buckets, 1-D tensors all-reduced), sharded AdamW, bf16 weights "
-                    "all-gathered under the next forward")
-        return f"{self.exchange} all-reduce per backward segment ({n} buckets), overlapped with backward"
+                    f"all-gathered under the next forward{via}")
+        return f"{self.exchange} all-reduce per backward segment ({n} buckets), overlapped with backward{via}"
 
     # ------------------------------------------------------------------ collectives (RCCL, or a host bounce under gloo)
     def _all_reduce(self, buf):
+        if self.comm is not None:
+            return self.comm.all_reduce(buf)
         if self.host_bounce:
             h = buf.float().cpu() if buf.dtype == torch.bfloat16 else buf.cpu()
             dist.all_reduce(h, group=self.pg)
@@ -380,6 +397,8 @@ class GradSync:
         return dist.all_reduce(buf, group=self.pg, async_op=True)
 
     def _reduce_scatter(self, out, buf):
+        if self.comm is not None:
+            return self.comm.reduce_scatter(out, buf)
         if self.host_bounce:               # gloo has no reduce-scatter: all-reduce on the host, keep this rank's chunk
             h = buf.float().cpu()
             dist.all_reduce(h, group=self.pg)
@@ -389,6 +408,8 @@ class GradSync:
         return dist.reduce_scatter_tensor(out, buf, group=self.pg, async_op=True)
 
     def _all_gather(self, out, mine):
+        if self.comm is not None:
+            return self.comm.all_gather(out, mine)
         if self.host_bounce:
             h = mine.float().cpu()
             parts = [torch.empty_like(h) for _ in range(self.world)]
@@ -500,7 +521,7 @@ class GradSync:
 class Trainer:
     def __init__(self, model, optimizer: FusedAdamW, schedule: Optional[LRSchedule] = None, clip_norm: float = 0.0,
                  microbatch_size: int = 256, process_group=None, log: Optional[Callable[[dict], None]] = None,
-                 exchange: str = "auto", single_rank_exchange: bool = False, dp_mode: str = "auto"):
+                 exchange: str = "auto", single_rank_exchange: bool = False, dp_mode: str = "auto", transport: str = "auto"):
         """dp_mode: "sharded" (reduce-scatter + sharded AdamW + all-gather of the bf16 weights, the reference's SHARD_GRAD_OP;
         default for N > 1 over RCCL) or "allreduce" (every rank runs the whole optimiser pass); "auto" also honours the
         MD_DP_MODE environment variable."""
@@ -511,8 +532,11 @@ class Trainer:
             dp_mode = os.environ["MD_DP_MODE"]
         if exchange == "auto" and os.environ.get("MD_DP_EXCHANGE"):
             exchange = os.environ["MD_DP_EXCHANGE"]
+        if transport == "auto":                # MD_COMM=native: the exchange through libmicrodit_comm.so instead of torch.distributed
+            transport = os.environ.get("MD_COMM", "torch")
         model.dit._ensure_flat()
-        self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange, mode=dp_mode)
+        self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange, mode=dp_mode,
+                             transport=transport)
         self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
         self.sharded = self.sync.enabled and self.sync.mode == "sharded"
@@ -615,7 +639,7 @@ class Trainer:
         f = self.model.dit.flat_buffers()
         bufs = [f["p"], self.opt.m, self.opt.v] + ([self.opt.ema] if self.opt.ema is not None else [])
         for t in bufs:
-            if self.sync.host_bounce:
+            if self.sync.torch_bounce:
                 h = t.cpu()
                 dist.broadcast(h, src=0, group=self.sync.pg)
                 t.copy_(h)
@@ -633,7 +657,7 @@ class Trainer:
         p = self.model.dit.flat_buffers()["s"].double()
         mine = torch.stack([p.sum(), (p * p).sum()])
         lo, hi = mine.clone(), mine.clone()
-        if self.sync.host_bounce:
+        if self.sync.torch_bounce:
             lo, hi = lo.cpu(), hi.cpu()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.sync.pg)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.sync.pg)

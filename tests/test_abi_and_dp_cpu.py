@@ -234,3 +234,27 @@ def test_shard_plan_partitions_every_bucket():
         assert nxt == own and covered + (small[1] - small[0]) == total
     with pytest.raises(ValueError):
         shard_plan([("rest", 0, 1024 * 3)], 7)
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """libmicrodit_comm.so (the gradient exchange on RCCL, SURVEY.md section 8b md_comm_*): builds without a GPU, exports every
+    function include/microdit_comm.h declares, and rejects malformed calls before it touches a device or RCCL."""
+    from micro_diffusion_amd import comm
+    path = comm.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "microdit_comm.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(md_comm_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) == 12, declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(comm.exported_symbols()), declared ^ set(comm.exported_symbols())
+    L = comm.lib()
+    assert L.md_comm_abi_version() == 1 == comm.ABI_VERSION
+    assert L.md_comm_unique_id(None) == -1
+    h = ctypes.c_void_p()
+    uid = ctypes.create_string_buffer(128)
+    assert L.md_comm_init(ctypes.byref(h), uid, 3, 2, 0) == -1          # rank >= world
+    assert L.md_comm_init(ctypes.byref(h), None, 0, 1, 0) == -1
+    assert L.md_comm_wait(None, 1, None) == -1 and L.md_comm_destroy(None) == -1
+    t = ctypes.c_int64(0)
+    assert L.md_comm_allreduce_bucket(None, None, 8, 0, None, ctypes.byref(t)) == -1

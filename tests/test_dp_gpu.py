@@ -121,7 +121,7 @@ def test_two_ranks_match_one_rank(hip, exchange, dp_mode):
     assert bad <= tol_frac, f"{bad:.2e} of the parameters differ by more than 1e-5 after one step"
 
 
-def _rccl_single_rank_main(port, exchange, out_path, dp_mode="allreduce"):
+def _rccl_single_rank_main(port, exchange, out_path, dp_mode="allreduce", transport="torch"):
     """One rank, backend "nccl" (= RCCL): every collective is the identity, but the calls are the production ones —
     asynchronous all-reduce on RCCL's stream behind an event on the compute stream, `work.wait()` as a stream dependency of
     the side stream that takes the bucket norms, the bf16 staging buffer feeding the optimiser kernel."""
@@ -132,8 +132,9 @@ def _rccl_single_rank_main(port, exchange, out_path, dp_mode="allreduce"):
         from micro_diffusion_amd.trainer import Trainer
         model, opt, tr, part = _build((0, BATCH), exchange, BATCH // 2)
         tr = Trainer(model, opt, tr.schedule, clip_norm=0.25, microbatch_size=BATCH // 2, exchange=exchange, single_rank_exchange=True,
-                     dp_mode=dp_mode)
+                     dp_mode=dp_mode, transport=transport)
         assert tr.sync.enabled and not tr.sync.host_bounce and tr.sync.exchange == exchange and tr.sync.mode == dp_mode
+        assert (tr.sync.comm is not None) == (transport == "native")
         seen = []
         inner = tr.sync._exchange
         tr.sync._exchange = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))[1]
@@ -159,8 +160,9 @@ def _rccl_single_rank_main(port, exchange, out_path, dp_mode="allreduce"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,dp_mode", [("bf16", "allreduce"), ("fp32", "allreduce"), ("bf16", "sharded")])
-def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode):
+@pytest.mark.parametrize("exchange,dp_mode,transport", [("bf16", "allreduce", "torch"), ("fp32", "allreduce", "torch"), ("bf16", "sharded", "torch"),
+                                                        ("bf16", "sharded", "native"), ("bf16", "allreduce", "native")])
+def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode, transport):
     """The RCCL transport itself needs N GPUs, which a 1-GPU box does not have; the code AROUND it (everything GradSync does
     under backend "nccl" that the gloo test above replaces by a host bounce) runs here on a one-rank communicator and must
     reproduce the step without any exchange."""
@@ -174,7 +176,7 @@ def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "r.pt")
         ctx = mp.get_context("spawn")
-        proc = ctx.Process(target=_rccl_single_rank_main, args=(_free_port(), exchange, out, dp_mode))
+        proc = ctx.Process(target=_rccl_single_rank_main, args=(_free_port(), exchange, out, dp_mode, transport))
         proc.start()
         proc.join(600)
         assert proc.exitcode == 0, f"RCCL single-rank process failed: {proc.exitcode}"
@@ -185,3 +187,50 @@ def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode):
     assert abs(r["gnorm"] - g1) <= tol_n * g1, (r["gnorm"], g1)
     bad = ((r["p"] - p1).abs() > 1e-5).float().mean().item()
     assert bad <= tol_frac, f"{bad:.2e} of the parameters differ by more than 1e-5 after one step"
+
+
+def _comm_direct_main(port, out_path):
+    """libmicrodit_comm.so by itself on a one-rank communicator: every collective is the identity, what is checked is the stream
+    contract -- a collective runs behind the kernels already enqueued on the caller's stream, the caller's later kernels run
+    behind wait(ticket), tickets are refused once recycled."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    from micro_diffusion_amd import comm
+    c = comm.Comm(comm.Comm.unique_id(), 0, 1, 0)
+    n = 1 << 24
+    a = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    ok = True
+    for it in range(4):
+        a.fill_(float(it + 1))                                   # compute stream: produce the bucket
+        t = c.all_reduce(a)                                      # comm stream, behind the fill
+        t.wait()                                                 # compute stream behind the collective
+        b = a.float().sum()                                      # consumer on the compute stream
+        ok = ok and float(b) == float(it + 1) * n
+    src = torch.arange(1024, device="cuda", dtype=torch.float32)
+    dst = torch.zeros(1024, device="cuda")
+    c.reduce_scatter(dst, src).wait()
+    g = torch.zeros(1024, device="cuda")
+    c.all_gather(g, dst).wait()
+    torch.cuda.synchronize()
+    ok = ok and torch.equal(dst, src) and torch.equal(g, src)
+    first = comm.Ticket(c, 1)
+    for _ in range(1100):                                        # more collectives than the ticket ring holds
+        last = c.all_reduce(dst)
+    last.wait()
+    stale = comm.lib().md_comm_wait(c.handle, first.ticket, torch.cuda.current_stream().cuda_stream)
+    c.synchronize()
+    c.destroy()
+    torch.save({"ok": bool(ok), "stale_rc": int(stale)}, out_path)
+
+
+def test_md_comm_stream_contract_on_one_rank(hip):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r.pt")
+        ctx = mp.get_context("spawn")
+        proc = ctx.Process(target=_comm_direct_main, args=(_free_port(), out))
+        proc.start()
+        proc.join(300)
+        assert proc.exitcode == 0, f"md_comm process failed: {proc.exitcode}"
+        r = torch.load(out)
+    assert r["ok"], "a collective did not see the bucket its stream order promises, or the consumer ran ahead of it"
+    assert r["stale_rc"] == -1, "a ticket whose event was recycled must be refused"
