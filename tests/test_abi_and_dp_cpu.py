@@ -258,3 +258,64 @@ def test_comm_library_exports_every_declared_symbol():
     assert L.md_comm_wait(None, 1, None) == -1 and L.md_comm_destroy(None) == -1
     t = ctypes.c_int64(0)
     assert L.md_comm_allreduce_bucket(None, None, 8, 0, None, ctypes.byref(t)) == -1
+
+
+def test_grouped_wgrad_host_logic():
+    """DiTEngine._wgrad_flush (host logic, no GPU): the weight gradients recorded for one block become ONE grouped launch whose
+    problem table mirrors the layout of the gradient tensors (offsets relative to the lowest one, a foreign tensor in between left
+    as a gap of the slice), with a split factor that divides the token count into multiples of 128, fits the workspace and reaches
+    the persistent kernel's 192 work items when the tiles allow it; one flat reduction per contiguous run."""
+    import types
+    from micro_diffusion_amd import hip
+    from micro_diffusion_amd.engine import DiTEngine
+
+    class T:                                   # a tensor stand-in: address only
+        def __init__(self, ptr):
+            self.ptr, self.dtype = ptr, None
+
+        def data_ptr(self):
+            return self.ptr
+
+    calls = {"gemm": [], "reduce": []}
+    L = types.SimpleNamespace(md_splitk_reduce_flat=lambda ws, out, n, stride, ks, acc, st: calls["reduce"].append((ws, out, n, stride, ks, acc)) or 0)
+
+    class WS:
+        def numel(self):
+            return 128 << 20
+
+        def data_ptr(self):
+            return 1 << 40
+    eng = DiTEngine.__new__(DiTEngine)
+    eng.ws, eng.L, eng.kernel_profile, eng.group_wgrad, eng._wgroup = WS(), L, None, True, None
+    eng._st = lambda: 0
+    eng._gemm = lambda **kw: calls["gemm"].append(kw)
+    base = 1 << 30
+    sizes = {"q.weight": (1024, 1024), "kv.weight": (2048, 1024), "xproj.weight": (1024, 1024), "w1.weight": (5632, 1024), "w3.weight": (1024, 2816)}
+    eng.G, off = {}, base
+    for k, (r, c) in sizes.items():            # laid out back to back in this order, like a block of the flat gradient buffer
+        eng.G[k] = T(off)
+        off += 4 * r * c
+    tokens = 16384
+    eng._wgrad_begin()
+    # recorded in backward order; kv (different token count in the real block) is NOT part of the group
+    eng.lin_wgrad(T(11), T(12), "w3", tokens, 1024, 2816, defer=True)
+    eng.lin_wgrad(T(13), T(14), "w1", tokens, 5632, 1024, defer=True)
+    eng.lin_wgrad(T(15), T(16), "xproj", tokens, 1024, 1024, defer=True)
+    eng.lin_wgrad(T(17), T(18), "q", tokens, 1024, 1024, defer=True)
+    assert not calls["gemm"], "deferred weight gradients must not launch before the flush"
+    eng._wgrad_flush()
+    assert len(calls["gemm"]) == 1
+    kw = calls["gemm"][0]
+    assert kw["n_problems"] == 4 and kw["K"] == tokens and kw["mode"] == hip.EPI_STORE_F32 and not kw["a_kcontig"] and not kw["b_kcontig"]
+    probs = sorted(kw["_problems"], key=lambda g: g["out"])
+    assert [g["out"] for g in probs] == [eng.G[k + ".weight"].data_ptr() for k in ("q", "xproj", "w1", "w3")]
+    span = (eng.G["w3.weight"].data_ptr() + 4 * 1024 * 2816 - base) // 4
+    assert kw["sSplit"] == span
+    ks = kw["ksplit"]
+    tiles = 16 + 16 + 22 * 4 + 4 * 11
+    assert (tokens // 128) % ks == 0 and ks * span <= (128 << 20) and tiles * ks >= 192 and ks <= 8, ks
+    # runs: [q] (kv follows it in memory but is not in the group), [xproj, w1, w3]
+    assert [(out, n) for _, out, n, _, _, _ in calls["reduce"]] == [(base, 1024 * 1024), (eng.G["xproj.weight"].data_ptr(), 1024 * 1024 + 5632 * 1024 + 1024 * 2816)]
+    assert all(stride == span and k_ == ks and acc == 1 for _, _, _, stride, k_, acc in calls["reduce"])
+    assert calls["reduce"][1][0] - calls["reduce"][0][0] == eng.G["xproj.weight"].data_ptr() - base     # slice offsets mirror the gradient layout
+    assert eng._wgroup == [] and not eng._wgrad_flush()                    # an empty group flushes to nothing
