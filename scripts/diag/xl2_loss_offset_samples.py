@@ -1,0 +1,50 @@
+"""Is the -0.48 % XL/2 loss offset of the two res-256 parity cases (B = 2) a systematic shrink or a draw?  Per-sample EDM loss of the
+HIP path against the fp32 oracle on 16 independent samples (4 synthetic weight / data seeds x batch 4, res_256_pretrain geometry,
+mask 0.75, forward only).  If the offset were systematic every sample would sit near -0.5 %; if it is the projection of bf16 noise
+onto the 16 output directions of a sample the per-sample offsets scatter around ~0 with that magnitude.
+    python scripts/diag/xl2_loss_offset_samples.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import microdit_ref as orc  # noqa: E402  (a diagnostic script: the oracle is the checker here, as in tests/)
+from micro_diffusion_amd import dit as mdit  # noqa: E402
+from micro_diffusion_amd.model import LatentDiffusion, _FrozenStub  # noqa: E402
+
+cfg = orc.xl2_config()
+B, ratio, pm, ps = 4, 0.75, -0.6, 1.2
+rel = []
+for seed in (141, 151, 161, 171):
+    sd = orc.synth_state_dict(cfg, seed)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1)
+    with torch.no_grad():
+        lat = batch["image_latents"].float()
+        cond = batch["caption_latents"].float() * batch["drop_caption_mask"].view(-1, 1, 1, 1)
+        _, parts = orc.edm_loss(sd, cfg, lat, cond, rnd, epsn, ratio, mnoise, pm, ps, return_parts=True)
+        sigma = parts["sigma"]
+        w = (sigma ** 2 + 0.81) / (sigma * 0.9) ** 2
+        l = F.avg_pool2d((w * (parts["D"] - lat) ** 2).mean(1), cfg.patch_size).flatten(1)
+        keep = 1 - parts["mask"]
+        o_ps = ((l * keep).sum(1) / keep.sum(1)).double()
+    d = mdit.DiT(**cfg.__dict__)
+    d.load_state_dict(sd, strict=True)
+    model = LatentDiffusion(d.to("cuda"), _FrozenStub("vae"), _FrozenStub("te"), _FrozenStub("tok"), p_mean=pm, p_std=ps, train_mask_ratio=ratio)
+    model.train()
+    model.dit.engine.keep_last_tape = True
+    with torch.no_grad():
+        model.edm_loss(batch["image_latents"].cuda(), (batch["caption_latents"] * batch["drop_caption_mask"].view(-1, 1, 1, 1).half()).cuda(),
+                       mask_ratio=ratio, _noise=(rnd.cuda(), epsn.cuda(), mnoise.cuda()))
+    h_ps = model.dit.engine.last_tape.loss_per_sample.double().cpu()
+    r = ((h_ps - o_ps) / o_ps).numpy()
+    rel += list(r)
+    print(f"seed {seed}: sigma {[round(float(s), 3) for s in sigma.flatten()]}  per-sample loss offset % {[round(100 * float(x), 3) for x in r]}  "
+          f"batch-mean offset {100 * float((h_ps.mean() - o_ps.mean()) / o_ps.mean()):+.3f} %", flush=True)
+    del model, d
+    torch.cuda.empty_cache()
+rel = np.array(rel)
+print(f"16 samples: mean {100 * rel.mean():+.3f} %  std {100 * rel.std(ddof=1):.3f} %  stderr {100 * rel.std(ddof=1) / 4:.3f} %  min {100 * rel.min():+.3f} %  max {100 * rel.max():+.3f} %  "
+      f"negative {int((rel < 0).sum())} / 16")
