@@ -2,7 +2,7 @@
 HIP path against the fp32 oracle on 16 independent samples (4 synthetic weight / data seeds x batch 4, res_256_pretrain geometry,
 mask 0.75, forward only).  If the offset were systematic every sample would sit near -0.5 %; if it is the projection of bf16 noise
 onto the 16 output directions of a sample the per-sample offsets scatter around ~0 with that magnitude.
-    python scripts/diag/xl2_loss_offset_samples.py"""
+    python tests/diag/xl2_loss_offset_samples.py"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-from oracle import microdit_ref as orc  # noqa: E402  (a diagnostic script: the oracle is the checker here, as in tests/)
+from oracle import microdit_ref as orc  # noqa: E402  (lives under tests/: the oracle is test infrastructure and only checks)
 from micro_diffusion_amd import dit as mdit  # noqa: E402
 from micro_diffusion_amd.model import LatentDiffusion, _FrozenStub  # noqa: E402
 
