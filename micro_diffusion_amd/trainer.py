@@ -3,15 +3,19 @@ torch.optim.AdamW + the LR scheduler do around `LatentDiffusion.forward` in the 
 configs/*.yaml), re-designed for one process per GPU with RCCL over xGMI:
 
   * the per-rank batch (global_batch / world_size, train.py:50) is split into microbatches of
-    `device_train_microbatch_size` (yaml trainer.device_train_microbatch_size); each microbatch loss is scaled by
-    n_micro / n_rank_batch before backward (Composer semantics); gradients accumulate in
-    the flat fp32 buffer;
-  * data parallelism = gradient averaging (numerically the reference's FSDP SHARD_GRAD_OP, yaml trainer.fsdp_config):
-    during the LAST microbatch's backward each finished segment (final layer, one DiT block, ...) of the flat
-    gradient buffer is all-reduced asynchronously — RCCL runs on its own stream and overlaps the remaining
-    backward kernels; no other collective exists on the data path;
-  * after the last bucket: one fused pass computes ||g||, one fused pass clips (coef from the device-side norm, no
-    host sync), applies AdamW, re-emits the bf16 shadow weights and zeroes the gradients.
+    `device_train_microbatch_size` (yaml trainer.device_train_microbatch_size); microbatch i contributes with weight
+    n_i / n_rank_batch (Composer semantics): `LatentDiffusion.train_microbatch` runs forward, loss and
+    the hand-written backward as one launch sequence (no autograd graph), the weight folded into md_edm_loss_train;
+    gradients accumulate in the flat fp32 buffer;
+  * data parallelism = the reference's FSDP SHARD_GRAD_OP (yaml trainer.fsdp_config): during the LAST microbatch's backward
+    each finished segment (final layer, one DiT block, ...) of the flat gradient buffer is staged as bf16 and reduce-scattered
+    asynchronously — RCCL runs on its own stream and overlaps the remaining backward kernels; every rank updates its chunk of
+    the weights / moments (FusedAdamW.step_sharded, one launch over a range table) and the fresh bf16 weights are all-gathered
+    bucket by bucket under the next forward (GradSync; `dp_mode="allreduce"` keeps the all-reduce form where every rank runs
+    the whole optimiser pass).  Transport: torch.distributed (default) or libmicrodit_comm.so (`transport="native"`);
+  * the squared gradient norm is taken per reduced bucket on a side stream behind its collective (fixed-order partial sums:
+    the clip coefficient is bit-identical on all ranks, no host sync), then one fused pass clips, applies AdamW, re-emits the
+    bf16 shadow weights and (all-reduce form) zeroes the gradients.
 """
 from __future__ import annotations
 
