@@ -2,7 +2,7 @@
 global batch 2048) on N MI355X GPUs — one full optimisation step per "step": all microbatches fwd+bwd, gradient
 exchange (N > 1), clip, AdamW.  Prints ONE JSON line (contract in the task description).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Extra keys of the line (the headline fields are unchanged by them):
@@ -203,6 +203,21 @@ def gemm_traffic():
     return (None if info["stale"] else t.get("bytes_per_launch")), info
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(n, argv):
+    """argv of the launcher `python bench.py --gpus N` (no WORLD_SIZE in the environment) re-executes itself under: N ranks of
+    this script on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", port, os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,15 +235,26 @@ def main():
     ap.add_argument("--attn-bwd", default="auto", choices=["auto", "pair", "fused1", "fused2", "fused2s"],
                     help="A/B runs: force one attention-backward kernel wherever it covers the shape (default: the library's rule)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rank-probe", action="store_true", help=argparse.SUPPRESS)   # tests: every rank reports itself and exits (no GPU needed)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         _cpu_baseline_worker()
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` is ONE command per node, like the reference's `composer train.py ...`
+        # (/root/reference/train_e2e.sh:10): it spawns its own N ranks (one process per GPU) and the ranks take the
+        # torch.distributed.run branch below.  exec, not a child: rank 0's JSON line is this command's stdout.
+        os.execv(sys.executable, self_launch_command(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.rank_probe:
+        print(json.dumps({"rank_probe": rank, "world": world, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        return
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` (it spawns its ranks) or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     ndev = torch.cuda.device_count()
     # MD_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the distributed path on a 1-GPU box)
     backend = os.environ.get("MD_DIST_BACKEND", "nccl")
