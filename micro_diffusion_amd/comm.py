@@ -36,18 +36,34 @@ def _source_hash() -> str:
 
 
 def build(force: bool = False) -> str:
-    """Compile csrc/comm/md_comm.cpp into libmicrodit_comm.so in-tree (idempotent; host code only: g++ + the HIP runtime)."""
+    """Compile csrc/comm/md_comm.cpp into libmicrodit_comm.so in-tree (idempotent; host code only: g++ + the HIP runtime).
+    With MD_COMM=native all N ranks of a node reach this together: an exclusive file lock serialises them (as hip.build does) and
+    the library is linked to a temporary name and renamed into place, so no rank can dlopen a half-written file."""
+    import fcntl
+    with open(os.path.join(_HERE, ".libmicrodit_comm.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool) -> str:
     want = _source_hash()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH):
         with open(_HASH_PATH) as fh:
             if fh.read().strip() == want:
                 return LIB_PATH
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, *CXX_FLAGS, "-I", _INCLUDE, "-I", os.path.join(ROCM, "include"), _SRC, "-o", LIB_PATH,
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [cxx, *CXX_FLAGS, "-I", _INCLUDE, "-I", os.path.join(ROCM, "include"), _SRC, "-o", tmp,
            "-L", os.path.join(ROCM, "lib"), "-lamdhip64", "-ldl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
-        raise RuntimeError(f"{cxx} failed on md_comm.cpp:\\n{r.stdout.decode(errors='replace')}")
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise RuntimeError(f"{cxx} failed on md_comm.cpp:\n{r.stdout.decode(errors='replace')}")
+    os.replace(tmp, LIB_PATH)
     with open(_HASH_PATH, "w") as fh:
         fh.write(want)
     return LIB_PATH

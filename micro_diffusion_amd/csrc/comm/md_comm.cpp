@@ -103,14 +103,11 @@ extern "C" int md_comm_unique_id(void* out) {
     return 0;
 }
 
-extern "C" int md_comm_init(md_comm** out, const void* uid, int32_t rank, int32_t world, int32_t device) {
-    if (!out || !uid || world < 1 || rank < 0 || rank >= world || device < 0) return MD_COMM_BAD_ARG;
-    if (!rccl().ok) return MD_COMM_NO_RCCL;
-    HIP_TRY(hipSetDevice(device));
-    md_comm* c = new md_comm();
-    c->rank = rank;
-    c->world = world;
-    c->device = device;
+extern "C" int md_comm_destroy(md_comm* c);
+
+namespace {
+// Everything md_comm_init can fail on after the struct exists; a failure leaves *c for the caller to tear down.
+int comm_setup(md_comm* c, const void* uid) {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));        // hi = the numerically lowest = highest priority
     HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
@@ -118,21 +115,45 @@ extern "C" int md_comm_init(md_comm** out, const void* uid, int32_t rank, int32_
     for (int i = 0; i < TICKETS; ++i) HIP_TRY(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
     ncclUniqueId id;
     memcpy(&id, uid, sizeof(id));
-    NCCL_TRY(rccl().CommInitRank(&c->comm, world, id, rank));
+    NCCL_TRY(rccl().CommInitRank(&c->comm, c->world, id, c->rank));
+    return 0;
+}
+}  // namespace
+
+extern "C" int md_comm_init(md_comm** out, const void* uid, int32_t rank, int32_t world, int32_t device) {
+    if (!out || !uid || world < 1 || rank < 0 || rank >= world || device < 0) return MD_COMM_BAD_ARG;
+    *out = nullptr;
+    if (!rccl().ok) return MD_COMM_NO_RCCL;
+    HIP_TRY(hipSetDevice(device));
+    md_comm* c = new md_comm();        // value-initialised: every handle null until created
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    const int rc = comm_setup(c, uid);
+    if (rc) {                          // nothing leaks: the stream, the events created so far and the struct go with destroy
+        const std::string why = g_err;   // the message of the call that failed, not of the teardown
+        (void)md_comm_destroy(c);
+        g_err = why;
+        return rc;
+    }
     *out = c;
     return 0;
 }
 
 extern "C" int md_comm_destroy(md_comm* c) {
     if (!c) return MD_COMM_BAD_ARG;
+    int rc = 0;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm) rccl().CommDestroy(c->comm);
+    if (c->comm) {
+        const ncclResult_t r = rccl().CommDestroy(c->comm);
+        if (r != ncclSuccess) rc = fail(std::string("ncclCommDestroy: ") + rccl().GetErrorString(r));
+    }
     for (int i = 0; i < TICKETS; ++i)
         if (c->done[i]) (void)hipEventDestroy(c->done[i]);
     if (c->order) (void)hipEventDestroy(c->order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-    return 0;
+    return rc;
 }
 
 extern "C" int md_comm_rank(const md_comm* c) { return c ? c->rank : MD_COMM_BAD_ARG; }

@@ -21,7 +21,8 @@ _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the fp32 buffers
 
 
 _BUCKET_ALIGN = 1024  # elements; every data-parallel bucket starts (and therefore ends) on a multiple of it, so a bucket splits
-#                       into equal, 128-byte aligned rank chunks for any world size up to 16 (reduce-scatter / all-gather in place)
+#                       into equal, 128-byte aligned rank chunks for every world size that divides 16 (2, 4, 8, 16: reduce-scatter /
+#                       all-gather in place).  Other world sizes (3, 5, 6, 7) keep the all-reduce exchange (trainer.GradSync "auto")
 
 
 def flat_layout(table):
@@ -226,6 +227,11 @@ class DiT(nn.Module):
         detected through the parameters' autograd version counters, which every in-place update bumps."""
         f = self._flat
         ver = self._param_version()
+        if ver != self._shadow_version and getattr(self, "shadow_is_authoritative", False):
+            # sharded optimiser: this rank's fp32 masters of the OTHER ranks' chunks are stale and the bf16 shadow (all-gathered)
+            # is the only complete copy of the weights -- re-deriving it from the masters would silently corrupt them
+            raise RuntimeError("a parameter was modified in place while the sharded optimiser holds stale fp32 masters of foreign "
+                               "chunks: call Trainer.consolidate() first (it all-gathers masters and moments)")
         if force or ver != self._shadow_version:
             hip.check(hip.lib().md_cast_f32_bf16(f["p"].data_ptr(), f["s"].data_ptr(), f["total"], None,
                                                  torch.cuda.current_stream().cuda_stream), "md_cast_f32_bf16")

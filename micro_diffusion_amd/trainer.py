@@ -89,11 +89,19 @@ class FusedAdamW:
         self.v = torch.zeros_like(f["p"])
         self.sumsq = torch.zeros(1, device=f["p"].device)
         self.partials = torch.zeros(self.MAX_BUCKETS * hip.SUMSQ_PARTIALS, device=f["p"].device)
+        self.norm_slots = self.MAX_BUCKETS
         self.step_count = 0
         self.ema_smoothing, self.ema_start = ema_smoothing, int(ema_start)
         self.ema = torch.zeros_like(f["p"]) if ema_smoothing is not None else None
         self.ema_live = False
         self.last_grad_scale = 1.0
+
+    def ensure_norm_slots(self, n: int) -> None:
+        """Room for `n` per-bucket partial sums of the gradient norm (a model with more data-parallel buckets than MAX_BUCKETS:
+        the sharded exchange has no other way to form ||g||)."""
+        if n > self.norm_slots:
+            self.partials = torch.zeros(n * hip.SUMSQ_PARTIALS, device=self.partials.device)
+            self.norm_slots = n
 
     def _launch(self, off: int, n: int, lr: float, max_norm: float, grad_scale: float, ss, g_bf16_ptr, shadow_ptr, zero_grad: int,
                 ema_mode: int) -> None:
@@ -335,18 +343,30 @@ class GradSync:
         if exchange == "auto":
             exchange = "bf16" if (self.enabled and (dist.get_backend(process_group) == "nccl" or self.transport == "native")) else "fp32"
         assert exchange in ("bf16", "fp32")
-        if mode == "auto":
-            mode = "sharded" if (self.enabled and exchange == "bf16") else "allreduce"
-        assert mode in ("sharded", "allreduce")
-        if mode == "sharded" and exchange != "bf16":
-            raise ValueError("the sharded exchange stages gradients as bf16 (exchange='bf16')")
-        self.exchange, self.mode = exchange, mode
         f = dit.flat_buffers()
         buckets = f.get("buckets")
         if buckets is None:                                   # a bare table (CPU tests): derive the ranges here
             from .dit import bucket_ranges
             buckets = bucket_ranges(dit._table, f["offs"], f["total"])
         self.bucket_list = list(buckets)
+        self.mode_note = None
+        if mode == "auto":
+            mode = "sharded" if (self.enabled and exchange == "bf16") else "allreduce"
+            if mode == "sharded":
+                # buckets are multiples of dit._BUCKET_ALIGN = 1024 elements: they split into 64-element-aligned rank chunks when
+                # the world size divides 16 (2, 4, 8, 16).  Any other world size (3, 5, 6, 7 GPUs) keeps the all-reduce exchange,
+                # which has no such constraint; only an EXPLICIT mode="sharded" raises.
+                try:
+                    shard_plan(self.bucket_list, self.world)
+                except ValueError as e:
+                    mode = "allreduce"
+                    self.mode_note = f"world size {self.world}: {e}; falling back to the all-reduce exchange"
+                    import warnings
+                    warnings.warn("GradSync: " + self.mode_note)
+        assert mode in ("sharded", "allreduce")
+        if mode == "sharded" and exchange != "bf16":
+            raise ValueError("the sharded exchange stages gradients as bf16 (exchange='bf16')")
+        self.exchange, self.mode = exchange, mode
         # segment name reported by the engine -> its ranges ("rest" also flushes "small": both complete with the last segment)
         self.ranges: Dict[str, List[tuple]] = {}
         for key, lo, hi in self.bucket_list:
@@ -378,6 +398,9 @@ class GradSync:
             self.ssend = torch.zeros(max(own, 8), device=dev, dtype=torch.bfloat16)    # fresh bf16 weights of this rank's chunks
             # [small-region partial sums (SUMSQ_PARTIALS floats) | sum over the ranks' chunk norms (1 float)] -> md_sumsq_finish
             self.fin = torch.zeros(hip.SUMSQ_PARTIALS + 8, device=dev)
+
+    def norm_slots(self) -> int:
+        return 0 if self.norm_partials is None else self.norm_partials.numel() // hip.SUMSQ_PARTIALS
 
     def describe(self) -> str:
         if not self.enabled:
@@ -454,7 +477,10 @@ class GradSync:
             work = self._reduce_scatter(red, buf)
             slot = self.buckets
             self.buckets += 1
-            if self.norm_partials is not None and slot < FusedAdamW.MAX_BUCKETS:
+            if self.norm_partials is not None:
+                if slot >= self.norm_slots():
+                    raise RuntimeError(f"{slot + 1} reduce-scattered buckets but {self.norm_slots()} norm slots: size them with "
+                                       "FusedAdamW.ensure_norm_slots(len(bucket_list)) (the Trainer does)")
                 self._norm_after(work, red, True, self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS)
         elif small:
             work = self._all_reduce(buf)
@@ -463,7 +489,7 @@ class GradSync:
             work = self._all_reduce(buf)
             slot = self.buckets
             self.buckets += 1
-            if self.norm_partials is not None and slot < FusedAdamW.MAX_BUCKETS:
+            if self.norm_partials is not None and slot < self.norm_slots():
                 self._norm_after(work, buf, self.exchange == "bf16", self.norm_partials.data_ptr() + 4 * slot * hip.SUMSQ_PARTIALS)
         if work is not None:
             self.pending.append(work)
@@ -483,7 +509,7 @@ class GradSync:
         for w in self.pending:
             w.wait()
         self.pending = []
-        n = self.buckets if (self.norm_partials is not None and self.side is not None and 0 < self.buckets <= FusedAdamW.MAX_BUCKETS) else 0
+        n = self.buckets if (self.norm_partials is not None and self.side is not None and 0 < self.buckets <= self.norm_slots()) else 0
         if self.side is not None and self.buckets:
             torch.cuda.current_stream().wait_stream(self.side)
         self.last_buckets, self.last_bytes = self.buckets, self.step_bytes
@@ -541,6 +567,7 @@ class Trainer:
         model.dit._ensure_flat()
         self.sync = GradSync(model.dit, process_group, exchange=exchange, single_rank_exchange=single_rank_exchange, mode=dp_mode,
                              transport=transport)
+        optimizer.ensure_norm_slots(len(self.sync.bucket_list))     # one slot per bucket: the sharded norm has no other source
         self.sync.norm_partials = optimizer.partials
         self.world = self.sync.world
         self.sharded = self.sync.enabled and self.sync.mode == "sharded"
@@ -590,6 +617,7 @@ class Trainer:
             self.opt.step_sharded(self.sync, lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
                                   norm_slots=slots, chunk_of=self.shard_chunk_of)
             self.stale_foreign_chunks = self.world > 1
+            self.model.dit.shadow_is_authoritative = self.stale_foreign_chunks
         else:
             self.opt.step(lr=self.opt.lr * fac, max_norm=self.clip_norm, grad_scale=1.0 / self.world,
                           g_bf16=self.sync.gbf, norm_partials=slots * hip.SUMSQ_PARTIALS)
@@ -625,6 +653,7 @@ class Trainer:
                 if w is not None:
                     w.wait()
         self.stale_foreign_chunks = False
+        self.model.dit.shadow_is_authoritative = False
 
     def optimizer_ms(self, last: int = 0) -> Optional[float]:
         """Mean compute-stream time per step of the gradient-norm finish + AdamW pass (needs measure_comm; synchronises)."""
@@ -652,14 +681,22 @@ class Trainer:
         self.model.dit.refresh_shadow(force=True)
 
     def replicas_in_sync(self) -> bool:
-        """True when the weights of all ranks have the same checksum (sum and sum of squares in fp64, taken over the bf16 shadow
-        every rank computes with: under the sharded optimiser the fp32 masters of foreign chunks are deliberately stale); cheap
-        enough to run every few hundred batches."""
+        """True when the weights of all ranks have the same checksum (sum of squares per data-parallel bucket, taken over the bf16
+        shadow every rank computes with: under the sharded optimiser the fp32 masters of foreign chunks are deliberately stale);
+        one bandwidth pass over 2.3 GB, cheap enough to run every few hundred batches."""
         if self.world <= 1:
             return True
         self.sync.wait_gather()
-        p = self.model.dit.flat_buffers()["s"].double()
-        mine = torch.stack([p.sum(), (p * p).sum()])
+        # one fused md_sumsq per bucket over the bf16 shadow (fixed-order partial sums -> bit-identical on identical data); no
+        # fp64 copies of the 1.17 G weights on the step path
+        f = self.model.dit.flat_buffers()
+        L, st = hip.lib(), torch.cuda.current_stream().cuda_stream
+        P = hip.SUMSQ_PARTIALS
+        part = torch.zeros(P, device=f["s"].device)
+        mine = torch.zeros(len(self.sync.bucket_list), device=f["s"].device)
+        for i, (_, blo, bhi) in enumerate(self.sync.bucket_list):
+            hip.check(L.md_sumsq(f["s"].data_ptr() + 2 * blo, 1, bhi - blo, part.data_ptr(), st), "md_sumsq")
+            hip.check(L.md_sumsq_finish(part.data_ptr(), P, mine.data_ptr() + 4 * i, st), "md_sumsq_finish")
         lo, hi = mine.clone(), mine.clone()
         if self.sync.torch_bounce:
             lo, hi = lo.cpu(), hi.cpu()

@@ -236,6 +236,54 @@ def test_shard_plan_partitions_every_bucket():
         shard_plan([("rest", 0, 1024 * 3)], 7)
 
 
+def _worker_ws3(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from micro_diffusion_amd.trainer import GradSync
+        fake = _FakeDiT(rank)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            # what Trainer(dp_mode="auto") builds over RCCL: bf16 exchange, mode picked by GradSync
+            sync = GradSync(fake, exchange="bf16", mode="auto")
+        explicit = None
+        try:
+            GradSync(fake, exchange="bf16", mode="sharded")
+        except ValueError as e:
+            explicit = str(e)
+        q.put((rank, sync.mode, sync.mode_note, [str(w.message) for w in rec], explicit))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_auto_mode_falls_back_to_allreduce_when_world_does_not_divide_16():
+    """buckets are multiples of 1024 elements, so they split into aligned rank chunks only when the world size
+    divides 16.  GradSync(mode='auto') must not crash a 3-, 5-, 6- or 7-GPU run: it keeps the all-reduce exchange and says so;
+    only an explicit mode='sharded' raises."""
+    from micro_diffusion_amd import dit as mdit
+    from micro_diffusion_amd.trainer import shard_plan
+    m = mdit.MicroDiT_XL_2()
+    offs, total = mdit.flat_layout(m._table)
+    buckets = mdit.bucket_ranges(m._table, offs, total)
+    for world in (3, 5, 6, 7):
+        with pytest.raises(ValueError):
+            shard_plan(buckets, world)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ws3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, mode, note, warns, explicit in res:
+        assert mode == "allreduce" and note and "world size 3" in note, (rank, mode, note)
+        assert any("falling back to the all-reduce exchange" in w for w in warns)
+        assert explicit and "does not split into 3" in explicit
+
+
 def test_comm_library_exports_every_declared_symbol():
     """libmicrodit_comm.so (the gradient exchange on RCCL, SURVEY.md section 8b md_comm_*): builds without a GPU, exports every
     function include/microdit_comm.h declares, and rejects malformed calls before it touches a device or RCCL."""
