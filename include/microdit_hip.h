@@ -303,14 +303,6 @@ int md_adamw_step(const md_adamw_args* a, hipStream_t stream);
 #define MD_ADAMW_MAX_RANGES 64
 int md_adamw_step_ranges(const md_adamw_args* a, const int64_t* flat_off, const int64_t* count, int32_t n_ranges, hipStream_t stream);
 
-/* ------------------------------------------------------------------------------------------- probes (tests only) */
-int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream);
-int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream);
-/* vmcnt ordering: per lane one cold 16-byte load (lanes spread over `cold_bytes`), four hot stores, s_waitcnt vmcnt(4);
- * *stale_lanes += lanes whose load had NOT landed (0 = loads and stores retire the counter in issue order). */
-int md_debug_vmcnt_order_probe(const void* cold, int64_t cold_bytes, void* hot, uint32_t* stale_lanes, int32_t blocks,
-                               hipStream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -245,9 +245,6 @@ _sig("md_sumsq", P, I32, I64, P, P)
 _sig("md_sumsq_finish", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_adamw_step_ranges", POINTER(AdamWArgs), P, P, I32, P)
-_sig("md_debug_tr_probe", P, P, P)
-_sig("md_debug_mfma_probe", P, P, P, P)
-_sig("md_debug_vmcnt_order_probe", P, I64, P, P, I32, P)
 
 
 def _declare(l: ctypes.CDLL) -> None:

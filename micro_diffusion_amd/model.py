@@ -96,9 +96,9 @@ class LatentDiffusion(nn.Module):
                 conditioning = self.text_encoder.encode(captions, attention_mask=batch["attention_mask"].view(-1, captions.shape[-1]))[0]
             else:
                 conditioning = self.text_encoder.encode(captions)[0]
-        # Dropped captions (model.py:131-135 multiplies the batch tensor by the 0/1 mask in place): here the mask rides along
-        # as a per-sample row scale of the first kernel that touches the captions (md_cast_rows_bf16), so no torch op runs and
-        # the batch tensor is left as the loader produced it.
+        # Dropped captions (model.py:131-135 multiplies the batch tensor by the 0/1 mask in place; forward() does the same).  For
+        # the Trainer's microbatch loop the mask rides along as a per-sample row scale of the first kernel that touches the
+        # captions (md_cast_rows_bf16): no torch op on the step path.
         drop = batch.get("drop_caption_mask") if hasattr(batch, "get") else None
         if drop is not None:
             drop = drop.reshape(-1)
@@ -107,12 +107,16 @@ class LatentDiffusion(nn.Module):
         return latents, conditioning, drop
 
     def forward(self, batch: dict):
-        """(loss, latents, conditioning) as model.py:104-142.  One deviation: the reference zeroes dropped captions by multiplying
-        the batch's caption tensor in place, so the tensor it returns (and the caller's batch) is modified; here the drop mask is
-        applied inside the first kernel that reads the captions and `conditioning` is returned as it came in."""
+        """(loss, latents, conditioning) as model.py:104-142, including its side effect: dropped captions are zeroed by an
+        IN-PLACE multiply of the conditioning tensor (model.py:131-135), so the returned `conditioning` -- and, with precomputed
+        latents, the caller's batch['caption_latents'], which is the same tensor -- hold zeros in the dropped rows, exactly what
+        a Composer callback / update_metric sees from the reference.  (This is the drop-in surface.  The Trainer's microbatch
+        loop, train_microbatch, leaves the batch as the loader produced it and applies the mask as a row scale inside the
+        first kernel that reads the captions; the mask is 0 / 1, so applying it on both routes is idempotent.)"""
         latents, conditioning, drop = self._inputs(batch)
-        loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio,
-                             _y_rowscale=drop)
+        if drop is not None:
+            conditioning *= drop.to(conditioning.dtype).view([-1] + [1] * (conditioning.dim() - 1))
+        loss = self.edm_loss(latents, conditioning, mask_ratio=self.train_mask_ratio if self.training else self.eval_mask_ratio)
         return (loss, latents, conditioning)
 
     def _draws(self, x: torch.Tensor, T: int, mask_ratio: float):

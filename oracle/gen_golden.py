@@ -244,7 +244,39 @@ def gen_sampler():
     print("tiny_sampler.npz")
 
 
+def gen_forward_return():
+    """What LatentDiffusion.forward RETURNS and what it does to its argument (model.py:104-142): (loss, latents, conditioning)
+    with `latents` / `conditioning` the batch's own tensors and the caption-drop mask multiplied into the conditioning IN PLACE
+    (model.py:131-135).  A drop-in caller (Composer's update_metric, an image-logging callback) sees exactly this."""
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, 11)
+    dit = ref_dit_from_cfg(cfg)
+    dit.load_state_dict(sd)
+    model = ref_latent_diffusion(dit, -0.6, 1.2, 0.75)
+    model.train()
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 12)
+    batch["drop_caption_mask"] = torch.tensor([1., 0., 1., 0.])           # two dropped samples, whatever the seed drew
+    rec = Recorded([rnd, epsn], [mnoise])
+    model.randn_like = lambda x: rec.randn()
+    bcopy = {k: v.clone() for k, v in batch.items()}
+    with mock.patch.object(torch, "randn", rec.randn), mock.patch.object(torch, "rand", rec.rand):
+        loss, lat, cond = model(bcopy)
+    out = {"loss": np.float64(loss.item()), "drop_caption_mask": batch["drop_caption_mask"].numpy(),
+           "latents_is_batch_tensor": np.bool_(lat is bcopy["image_latents"]),
+           "conditioning_is_batch_tensor": np.bool_(cond is bcopy["caption_latents"]),
+           "conditioning_dtype": np.array(str(cond.dtype)), "latents_dtype": np.array(str(lat.dtype)),
+           "caption_abs_sum_before": batch["caption_latents"].float().abs().flatten(1).sum(1).numpy(),
+           "caption_abs_sum_returned": cond.float().abs().flatten(1).sum(1).numpy(),
+           "caption_abs_sum_in_batch_after": bcopy["caption_latents"].float().abs().flatten(1).sum(1).numpy(),
+           "latents_unchanged": np.bool_(torch.equal(bcopy["image_latents"], batch["image_latents"]))}
+    np.savez_compressed(os.path.join(OUT, "tiny_forward_return.npz"), **out)
+    print("tiny_forward_return.npz", {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "forward_return":
+        gen_forward_return()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "res512":
         gen_model("tiny512_mask75", orc.tiny512_config(), 2, 14, 0.75, 0.0, 0.6, 77)
         sys.exit(0)
@@ -278,3 +310,4 @@ if __name__ == "__main__":
     gen_model("tiny512_mask75", orc.tiny512_config(), 2, 14, 0.75, 0.0, 0.6, 77)
     gen_init()
     gen_sampler()
+    gen_forward_return()

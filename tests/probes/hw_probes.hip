@@ -1,6 +1,8 @@
-// Hardware-semantics probes (test infrastructure only; not on the product path).
-#include "md_common.h"
-#include "../../include/microdit_hip.h"
+// Hardware-semantics probes: TEST INFRASTRUCTURE, built into tests/probes/libmd_probes.so (tests/probes/__init__.py), never
+// into the product library and not part of its C ABI (include/microdit_hip.h).  They pin down the three hardware behaviours
+// the hand-scheduled GEMM relies on: the ds_read_b64_tr_b16 lane map, the v_mfma_f32_32x32x16_bf16 operand / accumulator
+// layout, and in-order retirement of a wave's loads and stores in vmcnt.
+#include "../../micro_diffusion_amd/csrc/md_common.h"
 
 namespace {
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -56,21 +58,19 @@ __global__ __launch_bounds__(256) void vmcnt_order_probe_kernel(const u32x4* col
 }
 }  // namespace
 
-extern "C" int md_abi_version(void) { return MD_ABI_VERSION; }
-
-extern "C" int md_debug_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream) {
+extern "C" int mdp_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, stream, addr_elems, out);
     MD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int md_debug_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream) {
+extern "C" int mdp_mfma_probe(const void* A, const void* B, float* D, hipStream_t stream) {
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)A, (const bf16*)B, D);
     MD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int md_debug_vmcnt_order_probe(const void* cold, int64_t cold_bytes, void* hot, uint32_t* stale_lanes, int32_t blocks,
+extern "C" int mdp_vmcnt_order_probe(const void* cold, int64_t cold_bytes, void* hot, uint32_t* stale_lanes, int32_t blocks,
                                           hipStream_t stream) {
     if (!cold || !hot || !stale_lanes || blocks <= 0) return MD_BAD_ARG;
     const int64_t lanes = (int64_t)blocks * 256;

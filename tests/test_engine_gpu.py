@@ -216,10 +216,19 @@ def test_xl2_train_step_parity(hip, tag, prefer):
     dot = float(sum((grads[k].double() * og[k].double()).sum() for k in grads))
     # ---- the same forward with the ORACLE's expert-choice indices injected into every routed layer: what is left of the loss /
     # residual-stream difference is bf16 arithmetic; what disappeared was top-k slots ranked differently by bf16 gate logits
+    # -- forward AND backward: with the routing equalised every tensor -- gate weights, the LayerNorm that feeds the router and
+    # the expert weights of the 20 routed layers included -- must meet the 15 % per-tensor bound of the small configs
     eng.route_override = {k[len("route::"):]: v for k, v in o["taps"].items() if k.startswith("route::")}
-    with torch.no_grad():
-        loss_r = model.edm_loss(batch["image_latents"].cuda(), cond, mask_ratio=ratio, _noise=noise)
+    for prm in model.dit.parameters():
+        prm.grad = None                                  # attach_grads() re-creates the views over a zeroed accumulator
+    loss_r = model.edm_loss(batch["image_latents"].cuda(), cond, mask_ratio=ratio, _noise=noise)
+    loss_r.backward()
     torch.cuda.synchronize()
+    grads_r = {k: p.grad.detach().cpu() for k, p in model.dit.named_parameters()}
+    per_r = {k: _rel_rms(grads_r[k], og[k]) for k in grads_r}
+    gn_r = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads_r.values())))
+    dot_r = float(sum((grads_r[k].double() * og[k].double()).sum() for k in grads_r))
+    loss_r = loss_r.detach()
     drift_r = _block_drift(eng.last_tape, o["taps"], cfg)
     gain_r = _block_drift(eng.last_tape, o["taps"], cfg, fn=_gain)
     F_hip = eng.sample_image(eng.last_tape).float().cpu()
@@ -257,8 +266,9 @@ def test_xl2_train_step_parity(hip, tag, prefer):
     every4 = mixer_keys[-1:] + [k for k in drift if k.startswith("blocks.") and int(k.split(".")[1]) % 4 == 3]
     rep = {"case": f"{tag}_{prefer}", "loss_hip": loss.item(), "loss_oracle": o["loss"], "loss_rel_diff": (loss.item() - o["loss"]) / o["loss"],
            "loss_hip_oracle_routing": loss_r.item(), "loss_rel_diff_oracle_routing": (loss_r.item() - o["loss"]) / o["loss"],
-           "gnorm_hip": gn_h, "gnorm_oracle": gn_o,
-           "cosine": dot / (gn_h * gn_o), "gemm_launches": len(eng.gemm_log), "variants_requested": sorted(used),
+           "gnorm_hip": gn_h, "gnorm_oracle": gn_o, "gnorm_hip_oracle_routing": gn_r,
+           "cosine": dot / (gn_h * gn_o), "cosine_oracle_routing": dot_r / (gn_r * gn_o),
+           "worst_oracle_routing": sorted(per_r.items(), key=lambda kv: -kv[1])[:12], "gemm_launches": len(eng.gemm_log), "variants_requested": sorted(used),
            "network_output_F_oracle_routing": F_rep,
            "residual_stream_gain_oracle_routing": {k: gain_r[k] for k in every4},
            "residual_stream_rel_rms": {k: drift[k] for k in every4},
@@ -285,5 +295,10 @@ def test_xl2_train_step_parity(hip, tag, prefer):
     def routed(name):
         pre = ".".join(name.split(".")[:2])
         return pre in moe_blocks and (".mlp." in name or ".norm3." in name)
-    bad = {k: v for k, v in per.items() if v > (0.40 if routed(k) else 0.15)}
+    bad = {k: v for k, v in per.items() if v > (0.40 if routed(k) else 0.15)}      # the 40 % allowance: own routing ONLY
     assert not bad, bad
+    # ---- with the oracle's routing: the network output meets the 3 % bar and EVERY gradient tensor 15 %
+    assert F_rep["rel_rms"] <= 0.03, F_rep["rel_rms"]
+    assert rep["cosine_oracle_routing"] >= 0.99 and abs(gn_r - gn_o) <= 0.03 * gn_o, (rep["cosine_oracle_routing"], gn_r, gn_o)
+    bad_r = {k: v for k, v in per_r.items() if v > 0.15}
+    assert not bad_r, bad_r

@@ -4,6 +4,8 @@ layouts, ragged sizes, every epilogue.  Tolerance: fp32-accumulated bf16 product
 import pytest
 import torch
 
+from tests import probes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -35,7 +37,7 @@ def test_mfma_probe(hip):
     A = torch.randn(32, 16, device=dev).to(torch.bfloat16)
     B = torch.randn(16, 32, device=dev).to(torch.bfloat16)
     D = torch.zeros(32, 32, device=dev)
-    hip.check(hip.lib().md_debug_mfma_probe(A.data_ptr(), B.data_ptr(), D.data_ptr(), hip.stream_ptr()), "probe")
+    hip.check(probes.lib().mdp_mfma_probe(A.data_ptr(), B.data_ptr(), D.data_ptr(), hip.stream_ptr()), "probe")
     torch.cuda.synchronize()
     ref = A.float() @ B.float()
     assert (D - ref).abs().max().item() < 1e-3
@@ -52,7 +54,7 @@ def test_tr_read_semantics(hip):
         addr[l] = (li >> 2) * pitch + g * 16 + (li & 3) * 4
     out = torch.zeros(256, dtype=torch.int16, device=dev)
     a = addr.to(dev)
-    hip.check(hip.lib().md_debug_tr_probe(a.data_ptr(), out.data_ptr(), hip.stream_ptr()), "tr probe")
+    hip.check(probes.lib().mdp_tr_probe(a.data_ptr(), out.data_ptr(), hip.stream_ptr()), "tr probe")
     torch.cuda.synchronize()
     got = out.cpu().view(64, 4)
     exp = torch.zeros(64, 4, dtype=torch.int16)
@@ -187,7 +189,7 @@ def test_vmcnt_retires_loads_and_stores_in_issue_order(hip):
     flush = torch.empty(1 << 27, device=dev, dtype=torch.float32)
     for rep in range(8):
         flush.normal_()                                                              # evict `cold` from the caches between rounds
-        hip.check(hip.lib().md_debug_vmcnt_order_probe(cold.data_ptr(), cold.numel() * 4, hot.data_ptr(), stale.data_ptr(), 4096,
+        hip.check(probes.lib().mdp_vmcnt_order_probe(cold.data_ptr(), cold.numel() * 4, hot.data_ptr(), stale.data_ptr(), 4096,
                                                        hip.stream_ptr()), "probe")
     torch.cuda.synchronize()
     assert int(stale.item()) == 0, f"{int(stale.item())} lanes saw a store retire ahead of an older load"

@@ -149,3 +149,18 @@ def test_xl2_forward_matches_reference(tag, ckw, B, seed, ratio, pm, ps):
     if ratio > 0:
         assert np.array_equal(mask.numpy(), z["mask"])
     assert len(z["grad_keys"]) == 476          # 478 state_dict entries minus the two buffers
+
+
+def test_forward_return_fixture_is_what_the_oracle_computes():
+    """tests/golden/tiny_forward_return.npz (recorded from the reference's LatentDiffusion.forward): its loss is the oracle's
+    loss on the same batch with the same forced drop mask, and the returned conditioning is caption * mask."""
+    z = np.load(os.path.join(G, "tiny_forward_return.npz"))
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, 11)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 12)
+    batch["drop_caption_mask"] = torch.from_numpy(z["drop_caption_mask"])
+    loss = orc.latent_diffusion_forward(sd, cfg, batch, rnd, epsn, mnoise, 0.75, -0.6, 1.2)
+    assert abs(loss.item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
+    want = (batch["caption_latents"] * batch["drop_caption_mask"].view(-1, 1, 1, 1).half()).float().abs().flatten(1).sum(1).numpy()
+    assert np.allclose(want, z["caption_abs_sum_returned"], rtol=1e-6)
+    assert bool(z["conditioning_is_batch_tensor"]) and bool(z["latents_is_batch_tensor"]) and bool(z["latents_unchanged"])

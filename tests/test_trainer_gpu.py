@@ -275,6 +275,43 @@ def test_train_microbatch_equals_autograd_path(hip):
     assert abs(l1.item() - ol.item()) <= 0.01 * abs(ol.item())
 
 
+def test_forward_returns_what_the_reference_returns(hip):
+    """LatentDiffusion.forward(batch) -> (loss, latents, conditioning) against the tuple recorded from the reference itself
+    (tests/golden/tiny_forward_return.npz, oracle/gen_golden.py forward_return; model.py:104-142): `latents` and `conditioning`
+    are the batch's own tensors, the caption-drop mask is multiplied into the conditioning IN PLACE (the returned tensor AND the
+    caller's batch hold zeros in the dropped rows), the latents are untouched, dtypes are the loader's fp16, the loss matches."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_forward_return.npz"))
+    cfg = orc.tiny_config()
+    sd = orc.synth_state_dict(cfg, 11)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 12)
+    batch["drop_caption_mask"] = torch.from_numpy(z["drop_caption_mask"])
+    gb = {k: t.cuda() for k, t in batch.items()}
+    m = _product(cfg, sd)
+    m._noise_fn = lambda b: (rnd.cuda(), epsn.cuda(), mnoise.cuda())
+    lat_before = gb["image_latents"].clone()
+    loss, lat, cond = m(gb)
+    torch.cuda.synchronize()
+    assert bool(z["latents_is_batch_tensor"]) and lat is gb["image_latents"]
+    assert bool(z["conditioning_is_batch_tensor"]) and cond is gb["caption_latents"]
+    assert str(cond.dtype) == str(z["conditioning_dtype"]) and str(lat.dtype) == str(z["latents_dtype"])
+    assert bool(z["latents_unchanged"]) and torch.equal(lat, lat_before)
+    got = cond.float().abs().flatten(1).sum(1).cpu().numpy()
+    assert np.allclose(got, z["caption_abs_sum_returned"], rtol=1e-5) and np.allclose(got, z["caption_abs_sum_in_batch_after"], rtol=1e-5)
+    assert (got[z["drop_caption_mask"] == 0] == 0).all() and (got[z["drop_caption_mask"] == 1] > 0).all()
+    assert torch.equal(cond.cpu(), batch["caption_latents"] * batch["drop_caption_mask"].view(-1, 1, 1, 1).half())
+    assert abs(loss.item() - float(z["loss"])) <= 0.01 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
+    # the Trainer's route (train_microbatch: the mask as a row scale inside the first caption kernel) gives the same loss and
+    # leaves ITS batch as the loader produced it
+    gb2 = {k: t.cuda() for k, t in batch.items()}
+    caps = gb2["caption_latents"].clone()
+    m2 = _product(cfg, sd)
+    m2._noise_fn = lambda b: (rnd.cuda(), epsn.cuda(), mnoise.cuda())
+    l2 = m2.train_microbatch(gb2)
+    torch.cuda.synchronize()
+    assert torch.equal(gb2["caption_latents"], caps)
+    assert abs(l2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+
+
 def test_grouped_deferred_dgrads_equal_per_layer(hip):
     """The condition-vector gradients of all adaLN layers of a group (ONE operand-list launch, md_gemm_args.A_list / B_list,
     one slice per layer part) and the caption-token gradients of all cross-attention kv projections of a group (ONE launch over
