@@ -262,6 +262,8 @@ def main():
     dp = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from micro_diffusion_amd.trainer import cap_rccl_channels
+        channels = cap_rccl_channels()     # NCCL_MAX_NCHANNELS, before RCCL starts (an exported value wins)
         if backend == "nccl":
             if ndev < world:
                 raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, found {ndev} "
@@ -283,7 +285,7 @@ def main():
         if counted != world:
             raise SystemExit(f"all-reduce of ones returned {counted}, expected {world} ranks")
         dp = {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "rccl_ranks": counted if backend == "nccl" else 0,
-              "ranks": counted, "devices_visible": ndev}
+              "ranks": counted, "devices_visible": ndev, "rccl_max_channels": channels}
 
     head = Stage("res_256_pretrain", args.arch, args.global_batch, args.microbatch, world, rank)
     head.trainer.measure_comm = world > 1
@@ -313,6 +315,7 @@ def main():
         dp.update(mode=sync.mode, transport=("md_comm (libmicrodit_comm.so over RCCL)" if sync.comm is not None else "torch.distributed"),
                   exchange_dtype=sync.exchange, buckets=sync.last_buckets, bytes_per_step=sync.last_bytes,
                   optimizer_ms=head.trainer.optimizer_ms(last=args.steps),
+                  gemm_cu_limit_while_comm_in_flight=(256 - head.trainer.rccl_channels) if head.trainer.rccl_channels else None,
                   exposed_comm_ms=ex, exposed_comm_share=(ex / ms_per_step if ex is not None else None),
                   note="exposed_comm_ms = time the compute stream waited for the gradient exchange (and the side-stream bucket "
                        "norms) after the last backward kernel, mean over the timed steps of rank 0; criterion for moving the "

@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MD_ABI_VERSION 3
+#define MD_ABI_VERSION 4
 int md_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM */
@@ -100,6 +100,12 @@ typedef struct md_gemm_args {
      * entries; A / B / M / N / lda / ldb / sC of the struct are ignored, K / ksplit / sSplit are shared. */
     const md_gemm_problem* problems;
     int32_t n_problems;
+    /* PP256 only: upper bound on the workgroups (= CUs) the persistent kernel occupies; 0 = all 256.  The data-parallel step
+     * sets 256 - (RCCL channels) while a collective is in flight: an RCCL kernel holds one CU per channel for its whole duration
+     * and a PP256 workgroup fills a CU (128 KiB LDS, every VGPR), so with 256 workgroups the ones that find their CU taken start
+     * only when another workgroup has finished its whole tile list -- the launch takes up to twice as long; with the smaller grid
+     * the same tiles are dealt to the CUs that are free (ceil(tiles / (256 - k)) rounds). */
+    int32_t cu_limit;
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot

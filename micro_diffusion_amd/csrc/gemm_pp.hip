@@ -622,7 +622,8 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
 int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
     PPPlan w;
     if (!md_gemm_pp_plan(a, &w)) return MD_BAD_ARG;
-    const unsigned G = (unsigned)(w.total < NUM_CU ? w.total : NUM_CU);
+    const int cus = (a->cu_limit > 0 && a->cu_limit < NUM_CU) ? a->cu_limit : NUM_CU;     // md_gemm_args.cu_limit: CUs left to a collective
+    const unsigned G = (unsigned)(w.total < cus ? w.total : cus);
     const dim3 grid(G, 1, 1), block(512);
     const int epi = md_gemm_pp_epi_kind(a);
 #define PP_LAUNCH(AK, BK, E) hipLaunchKernelGGL((gemm_bf16_pp_kernel<AK, BK, E>), grid, block, 0, stream, *a, w)

@@ -132,6 +132,8 @@ class DiTEngine:
         self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
+        self.cu_limit_fn = None     # data parallelism: callable() -> CUs the persistent GEMM may occupy right now (0 = all): the
+        #                             Trainer leaves the CUs of RCCL's channels free while a collective is in flight
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
@@ -182,6 +184,8 @@ class DiTEngine:
             e0.record()
         chosen = self._chosen
         a.chosen_variant = ctypes.addressof(chosen)
+        if self.cu_limit_fn is not None:
+            a.cu_limit = self.cu_limit_fn()
         rc = hip.NOT_ELIGIBLE
         want = self.gemm_prefer if self.gemm_prefer != hip.GEMM_AUTO else a.variant
         if want != hip.GEMM_AUTO:

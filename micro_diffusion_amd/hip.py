@@ -99,6 +99,7 @@ class GemmProblem(Structure):
 
 
 GEMM_MAX_PROBLEMS = 8
+NUM_CU = 256            # MI355X; md_gemm_args.cu_limit is counted against it
 
 
 class GemmArgs(Structure):
@@ -114,12 +115,12 @@ class GemmArgs(Structure):
         ("batch", c_int32), ("ksplit", c_int32), ("a_kcontig", c_int32), ("b_kcontig", c_int32),
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
         ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p), ("list_segments", c_int32),
-        ("problems", c_void_p), ("n_problems", c_int32),
+        ("problems", c_void_p), ("n_problems", c_int32), ("cu_limit", c_int32),
     ]
 
 
 _lib = None
-ABI_VERSION = 3        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
+ABI_VERSION = 4        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
 
 
 def lib() -> ctypes.CDLL:
@@ -269,7 +270,7 @@ def stream_ptr():
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
-         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None):
+         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None, cu_limit=0):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
     def ptr(x):
         if x is None:
@@ -278,7 +279,7 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
-                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0)
+                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0, cu_limit)
     ch = ctypes.c_int32(-1)
     a.chosen_variant = ctypes.addressof(ch)
     rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())

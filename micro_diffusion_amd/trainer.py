@@ -278,6 +278,27 @@ class FusedAdamW:
         return FusedAdamW._EmaSwap(self)
 
 
+RCCL_CHANNELS_DEFAULT = 8      # CUs handed to RCCL per rank: 8 channels move the 2 x 2 GB of a step at well over the ~30 GB/s the
+#                                overlap needs (xGMI: 7 links x ~50 GB/s per direction); every channel costs the GEMMs 1 / 256
+
+
+def cap_rccl_channels(n: int = RCCL_CHANNELS_DEFAULT) -> int:
+    """Call BEFORE the process group / communicator is created: bounds the CUs RCCL's persistent kernels occupy
+    (NCCL_MAX_NCHANNELS; a value the user exported wins).  Returns the cap in force."""
+    import os
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(n, int(os.environ["NCCL_MAX_NCHANNELS"]))))
+    return rccl_channel_cap()
+
+
+def rccl_channel_cap() -> int:
+    import os
+    try:
+        return max(0, min(64, int(os.environ.get("NCCL_MAX_NCHANNELS", "0"))))
+    except ValueError:
+        return 0
+
+
 def shard_plan(buckets, world: int):
     """Rank chunks of the data-parallel buckets.  `buckets` = [(key, lo, hi)] tiling the flat buffer (dit.bucket_ranges; every
     boundary is a multiple of dit._BUCKET_ALIGN, so (hi - lo) / world is a whole number of 128-byte lines for world <= 16).
@@ -401,6 +422,11 @@ class GradSync:
 
     def norm_slots(self) -> int:
         return 0 if self.norm_partials is None else self.norm_partials.numel() // hip.SUMSQ_PARTIALS
+
+    def in_flight(self) -> bool:
+        """A collective of this exchange may be resident on the GPU right now (gradient buckets not yet waited for, or weight
+        all-gathers the next forward has not consumed)."""
+        return bool(self.pending) or bool(self.gather_work)
 
     def describe(self) -> str:
         if not self.enabled:
@@ -574,6 +600,13 @@ class Trainer:
         self.stale_foreign_chunks = False    # sharded: fp32 masters / moments of the other ranks' chunks are out of date
         self.shard_chunk_of = None           # measurement aid, see FusedAdamW.step_sharded
         model.dit._on_segment = self.sync.on_segment
+        # RCCL's kernels hold one CU per channel while a collective runs and a workgroup of the persistent GEMM needs a whole CU:
+        # leave those CUs out of the GEMM grids for as long as a collective is in flight (md_gemm_args.cu_limit; the channel
+        # count is capped by NCCL_MAX_NCHANNELS, which cap_rccl_channels() sets before the process group is created)
+        self.rccl_channels = rccl_channel_cap() if (self.sync.enabled and self.world > 1) else 0
+        if self.rccl_channels:
+            lim = hip.NUM_CU - self.rccl_channels
+            model.dit.engine.cu_limit_fn = lambda s=self.sync, lim=lim: (lim if s.in_flight() else 0)
         model.dit.engine.before_segment = self.sync.wait_gather if self.sharded else None
         # the Trainer runs forward -> backward strictly in turn: activations may live in the engine's fixed-address arenas
         model.dit._ensure_flat()

@@ -43,7 +43,7 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(build())
         P = c_void_p
         for name, args in (("mdp_tr_probe", [P, P, P]), ("mdp_mfma_probe", [P, P, P, P]),
-                           ("mdp_vmcnt_order_probe", [P, c_int64, P, P, c_int32, P])):
+                           ("mdp_vmcnt_order_probe", [P, c_int64, P, P, c_int32, P]), ("mdp_cu_hog", [c_int32, c_int64, P, P])):
             fn = getattr(_lib, name)
             fn.restype, fn.argtypes = c_int32, args
     return _lib

@@ -56,7 +56,25 @@ __global__ __launch_bounds__(256) void vmcnt_order_probe_kernel(const u32x4* col
     const unsigned long long m = __ballot(stale);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned)__popcll(m));
 }
+// A stand-in for an RCCL kernel on a single GPU: `blocks` workgroups that each hold a CU's LDS (96 KiB: a workgroup of the
+// persistent GEMM, 128 KiB, cannot share the CU) and spin for `ticks` of the 100 MHz wall clock.  tests/test_gemm_variants_gpu.py
+// uses it to show what md_gemm_args.cu_limit is for.
+__global__ __launch_bounds__(256) void cu_hog_kernel(long long ticks, unsigned* out) {
+    __shared__ unsigned char big[96 * 1024];
+    big[threadIdx.x] = (unsigned char)threadIdx.x;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0 && big[blockIdx.x & 255] == 77 && ticks < 0) atomicAdd(out, 1u);   // keeps `big` alive
+}
 }  // namespace
+
+extern "C" int mdp_cu_hog(int32_t blocks, int64_t microseconds, uint32_t* scratch, hipStream_t stream) {
+    if (blocks <= 0 || blocks > 256 || microseconds < 0 || !scratch) return MD_BAD_ARG;
+    hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(256), 0, stream, (long long)microseconds * 100, scratch);
+    MD_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mdp_tr_probe(const int32_t* addr_elems, int16_t* out, hipStream_t stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, stream, addr_elems, out);

@@ -190,3 +190,78 @@ def test_pp256_race_screen(hip, akc, bkc, variant):
     _close(outs[0], A.float() @ B.float().t(), rel=2e-3 if f32 else 2e-2, what="pp256")
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "pp256 result differs between identical launches (LDS ring race)"
+
+
+def _time_us(fn, reps=8):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e30
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def test_cu_limit_same_result_and_proportional_time(hip):
+    """md_gemm_args.cu_limit (data parallelism: the CUs of RCCL's channels are left out of the persistent kernel's grid while a
+    collective is in flight): the same plan on 256 - k workgroups gives bit-identical results, and costs what the smaller chip
+    costs -- time <= 256 / (256 - k) x 1.1 of the full-grid launch on a launch with many tiles per workgroup (12), where
+    whole-tile granularity does not dominate (1024 tiles on 248 workgroups are 5 rounds instead of 4 whatever the scheduler)."""
+    M, N, K, k = 65536, 3072, 1024, 8
+    torch.manual_seed(7)
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    C0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    C1 = torch.empty_like(C0)
+    kw = dict(A=A, B=B, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, variant=hip.GEMM_PP256)
+    t_full = _time_us(lambda: hip.gemm(C=C0, **kw))
+    t_lim = _time_us(lambda: hip.gemm(C=C1, cu_limit=256 - k, **kw))
+    assert torch.equal(C0, C1)
+    _close(C1[:512], A[:512].float() @ B.float().t(), what="cu_limit 248")
+    bound = 256 / (256 - k) * 1.1
+    print(f"cu_limit: full grid {t_full:.1f} us, {256 - k} workgroups {t_lim:.1f} us (x{t_lim / t_full:.3f}, bound x{bound:.3f})")
+    assert t_lim <= bound * t_full, (t_lim, t_full)
+
+
+def test_cu_limit_under_a_resident_collective(hip):
+    """What cu_limit is FOR, emulated on one GPU: 8 workgroups of a spinning kernel (tests/probes: 96 KiB of LDS each, so a
+    persistent-GEMM workgroup cannot share their CU -- an RCCL kernel with 8 channels) are resident on a side stream while
+    the GEMM runs.  With the full grid the 8 GEMM workgroups that find their CU taken start only when the hog leaves or another
+    workgroup finishes its whole tile list; with cu_limit = 248 every tile is dealt to a free CU.  Reported, and asserted only in
+    the direction that matters: the limited grid must not be slower than the full one while the CUs are held."""
+    from tests import probes
+    M, N, K = 65536, 1024, 1024                     # 4 tiles per workgroup: the full grid's late workgroups cost a whole extra pass
+    torch.manual_seed(8)
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kw = dict(A=A, B=B, C=C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, variant=hip.GEMM_PP256)
+    scratch = torch.zeros(1, device=dev, dtype=torch.int32)
+    side = torch.cuda.Stream()
+    t_free = _time_us(lambda: hip.gemm(**kw), reps=4)
+    res = {}
+    for name, lim in (("full", 0), ("limited", 248)):
+        best = 1e30
+        for _ in range(5):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):            # the hog is resident for 2 ms: far longer than one GEMM launch
+                hip.check(probes.lib().mdp_cu_hog(8, 2000, scratch.data_ptr(), side.cuda_stream), "hog")
+            torch.cuda._sleep(200000)                # let the hog's workgroups take their CUs first
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.gemm(cu_limit=lim, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3)
+        res[name] = best
+    print(f"cu_limit under 8 held CUs: free chip {t_free:.1f} us | full grid {res['full']:.1f} us | 248 workgroups {res['limited']:.1f} us")
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/cu_limit_under_hog.json", "w") as fh:
+        json.dump({"shape": [M, N, K], "held_cus": 8, "free_chip_us": t_free, "full_grid_us": res["full"], "limited_248_us": res["limited"]}, fh)
+    assert res["limited"] <= 1.05 * res["full"], res

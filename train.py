@@ -28,6 +28,9 @@ def train(cfg: dict):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from micro_diffusion_amd.trainer import cap_rccl_channels
+        cap_rccl_channels()       # NCCL_MAX_NCHANNELS before RCCL starts: the CUs its kernels hold are left out of the GEMM grids
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.manual_seed(cfg["seed"])                               # reproducibility.seed_all(cfg.seed)  (train.py:23)
     assert cfg["model"]["precomputed_latents"], "latents must be precomputed (train.py:25)"
