@@ -132,7 +132,7 @@ def _attn_ref(q, k, v, H, hd):
                                                     (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
                                                     (1, 2, 1024, 1024, 64, True), (2, 12, 256, 77, 64, False),
                                                     (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True)])
-@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4, 5])
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
     kernel pair (the only path for longer sequences); 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in
@@ -172,7 +172,7 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    covered = bwd_split in (0, 1) or max(Sq, Skv) <= 256
+    covered = bwd_split in (0, 1) or max(Sq, Skv) <= (96 if bwd_split == 5 else 256)    # 5: roles on separate waves, small buckets
     rc = L.md_attn_bwd(byref(a), st)
     if not covered:
         torch.cuda.synchronize()
@@ -193,7 +193,64 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
         assert r < 2e-2, f"{name} rel-rms {r}"
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,hd", [(3, 16, 64, 64, 64), (2, 16, 64, 77, 64), (2, 12, 256, 77, 64), (2, 3, 77, 77, 64),
+                                           (2, 4, 40, 77, 32), (2, 2, 16, 16, 32), (2, 5, 64, 96, 64), (2, 5, 96, 65, 64),
+                                           (1, 2, 130, 33, 32), (2, 4, 64, 128, 64)])
+@pytest.mark.parametrize("fwd_variant", [0, 1, 2])
+def test_attention_forward_variants(hip, B, H, Sq, Skv, hd, fwd_variant):
+    """md_attn_fwd's two kernels on the same problems: 1 = 32-key phases between barriers, 2 = K and V of the (batch, head) staged
+    whole behind one barrier (Skv <= 96; must refuse longer key sequences with -1 and write nothing), 0 = the library's rule.
+    Output and log-sum-exp against torch fp32 on the same bf16 inputs (cross-attention layout: q [B, Sq, hid], kv packed)."""
+    torch.manual_seed(B + H + Sq + Skv + hd)
+    L, st = hip.lib(), hip.stream_ptr()
+    hid = H * hd
+    qb = bf(torch.randn(B, Sq, hid, device=DEV))
+    kv = bf(torch.randn(B, Skv, 2 * hid, device=DEV))
+    k, v = kv[..., :hid], kv[..., hid:]
+    o = torch.full((B, Sq, hid), 3.0, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, Sq, device=DEV)
+    a = hip.AttnArgs(qb.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), None, None, None, None, None, B, H, Sq, Skv,
+                     hid, 2 * hid, 2 * hid, hid, Sq * hid, Skv * 2 * hid, Skv * 2 * hid, Sq * hid, 0, 0, 0, 0, 0, 0, 0, 0,
+                     1.0 / math.sqrt(hd), hd, 0, fwd_variant)
+    rc = L.md_attn_fwd(byref(a), st)
+    torch.cuda.synchronize()
+    if fwd_variant == 2 and Skv > 96:
+        assert rc == -1 and bool((o == 3.0).all()), "the short-key kernel must refuse Skv > 96 and launch nothing"
+        return
+    hip.check(rc, "attn fwd")
+    ref = _attn_ref(qb.float(), k.float(), v.float(), H, hd)
+    assert rel_rms(o, ref) < 1e-2, rel_rms(o, ref)
+    close(o, ref, rel=3e-2, what=f"attn out (variant {fwd_variant})")
+    qh = qb.float().view(B, Sq, H, hd).transpose(1, 2)
+    kh = k.float().reshape(B, Skv, H, hd).transpose(1, 2)
+    lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1)
+    assert (lse - lse_ref).abs().max().item() < 2e-2, (lse - lse_ref).abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("M,f", [(300, 512), (77 * 3 + 1, 2816), (1031, 776), (65536, 1792), (19, 8)])
+def test_swiglu_shapes(hip, M, f):
+    """md_swiglu_fwd / md_swiglu_bwd (dit.py:88-89) on ragged row counts (every tail of the 4-rows-per-step walk), widths that
+    are not a multiple of the 512-column wave span, padded leading dimensions, and one real XL/2 launch (65,536 x 1792)."""
+    torch.manual_seed(M + f)
+    L, st = hip.lib(), hip.stream_ptr()
+    ldh, lda = 2 * f + 16, f + 8
+    h12 = bf(torch.randn(M, ldh, device=DEV))
+    a = torch.full((M, lda), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_swiglu_fwd(h12.data_ptr(), ldh, a.data_ptr(), lda, M, f, st), "swiglu")
+    h1, h2 = h12[:, :f].float().requires_grad_(True), h12[:, f:2 * f].float().requires_grad_(True)
+    ar = F.silu(h1).bfloat16().float() * h2
+    da = bf(torch.randn(M, lda, device=DEV))
+    ar.backward(da[:, :f].float())
+    dh = torch.full((M, ldh), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.check(L.md_swiglu_bwd(da.data_ptr(), lda, h12.data_ptr(), ldh, dh.data_ptr(), ldh, M, f, st), "swiglu bwd")
+    torch.cuda.synchronize()
+    close(a[:, :f], ar, what="swiglu")
+    close(dh[:, :f], h1.grad, what="swiglu bwd d(h1)")
+    close(dh[:, f:2 * f], h2.grad, what="swiglu bwd d(h2)")
+    assert (a[:, f:] == 7.0).all() and (dh[:, 2 * f:] == 7.0).all(), "padding columns must not be written"
+
+
 def test_swiglu_gate_act_colsum(hip):
     torch.manual_seed(1)
     L, st = hip.lib(), hip.stream_ptr()
