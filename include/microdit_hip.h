@@ -194,12 +194,8 @@ typedef struct md_attn_args {
     int32_t bwd_split; /* backward kernel: 0 = the library picks (one fused launch per (batch, head) for Sq, Skv <= 256, else the
                           pair); forced (tests, A/B runs): 1 = the dQ + dK/dV pair, 2 = fused with Q, dO, K, V in LDS together,
                           3 = fused in two phases on half the LDS, 4 = the same with dK / dV as two passes for every size (3 does
-                          that for the 256-row buckets only), 5 = form 2 with the dQ role and the dK / dV role on separate waves of
-                          a larger workgroup (Sq, Skv <= 96).  A forced fused variant that does not cover the problem (Sq or
-                          Skv > 256; > 96 for 5) returns -1 and launches nothing. */
-    int32_t fwd_variant; /* forward kernel: 0 = the library picks (Skv <= 96: K and V staged whole behind one barrier; else 32-key
-                          phases); forced (tests, A/B runs): 1 = the phased kernel, 2 = the short-key kernel (-1, nothing launched,
-                          when Skv > 96) */
+                          that for the 256-row buckets only).  A forced fused variant that does not cover the problem (Sq or
+                          Skv > 256) returns -1 and launches nothing. */
 } md_attn_args;
 
 int md_attn_fwd(const md_attn_args* a, hipStream_t stream);

@@ -200,113 +200,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Forward for SHORT key sequences (Skv <= SKP <= 96: backbone self-attention over the 64 un-masked tokens, every cross-attention
-// to the 77 caption tokens, the caption block): the whole K and V of the (batch, head) are staged at once -- every global load of
-// the workgroup (Q fragments, K, V) is issued before the first LDS write, ONE barrier, then the key tiles are walked from LDS
-// without further synchronisation.  attn_fwd_kernel stages 32 keys per phase between two barriers: at Skv = 64..77 that is 2-3
-// dependent HBM round trips per workgroup whose arithmetic takes about one; the fused backward gained 1.9x from the same change
-// (profiles/r2_attention_two_phase_bwd.txt).  NT = threads of the workgroup (64 per 32 query rows).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int HD, int SKP, int NT>
-__global__ __launch_bounds__(NT) void attn_fwd_short_kernel(md_attn_args p) {
-    constexpr int PK = (HD + 8) * 2;
-    constexpr int CPR = HD / 8;
-    constexpr int ITK = (SKP * CPR + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SKP * PK];
-    unsigned char* sKall = smem;
-    unsigned char* sVall = smem + SKP * PK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int nw = NT / 64;
-    const int hh = lane >> 5;
-    const int64_t b = blockIdx.z, h = blockIdx.y;
-    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
-    const bool qvalid = q < p.Sq;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    u32x4 rq[HD / 16], rk[ITK], rv[ITK];
-#pragma unroll
-    for (int s = 0; s < HD / 16; ++s) rq[s] = qvalid ? *reinterpret_cast<const u32x4*>(Q + q * p.ldq + s * 16 + hh * 8) : z4;
-#pragma unroll
-    for (int it = 0; it < ITK; ++it) {
-        const int task = tid + it * NT, r = task / CPR, c = task % CPR;
-        const bool ok = task < SKP * CPR && r < p.Skv;
-        rk[it] = ok ? *reinterpret_cast<const u32x4*>(K + (int64_t)r * p.ldk + c * 8) : z4;
-        rv[it] = ok ? *reinterpret_cast<const u32x4*>(V + (int64_t)r * p.ldv + c * 8) : z4;
-    }
-#pragma unroll
-    for (int it = 0; it < ITK; ++it) {
-        const int task = tid + it * NT, r = task / CPR, c = task % CPR;
-        if (task < SKP * CPR) {
-            *reinterpret_cast<u32x4*>(sKall + r * PK + c * 16) = rk[it];
-            *reinterpret_cast<u32x4*>(sVall + r * PK + c * 16) = rv[it];
-        }
-    }
-    bf16x8 qf[HD / 16];
-#pragma unroll
-    for (int s = 0; s < HD / 16; ++s) qf[s] = __builtin_bit_cast(bf16x8, rq[s]);
-    f32x16 oacc[HD / 32];
-#pragma unroll
-    for (int di = 0; di < HD / 32; ++di)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[di][r] = 0.f;
-    float m = -1e30f, l = 0.f;
-    __syncthreads();
-    const int nk32 = (int)((p.Skv + 31) / 32);
-    for (int j = 0; j < nk32; ++j) {
-        const int64_t key0 = (int64_t)j * 32;
-        const unsigned char* sK = sKall + j * 32 * PK;
-        const unsigned char* sV = sVall + j * 32 * PK;
-        f32x16 sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < HD / 16; ++s)
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
-        float tmax = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float v = key < p.Skv ? sacc[r] * p.scale : -1e30f;
-            sacc[r] = v;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = __expf(m - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pr = __expf(sacc[r] - m_new);
-            sacc[r] = pr;
-            psum += pr;
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l = l * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int di = 0; di < HD / 32; ++di)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[di][r] *= alpha;
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const bf16x8 pf = pack8(sacc, 8 * sp);
-#pragma unroll
-            for (int di = 0; di < HD / 32; ++di)
-                oacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    tr_frag(sV, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, oacc[di], 0, 0, 0);
-        }
-    }
-    if (qvalid) {
-        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
-        store_rows<HD>(O, oacc, 1.f / l, lane);
-        if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = m + __logf(l);
-    }
-}
-
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
@@ -502,11 +395,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
 // launches (the split kernels read Q, K, V, dO twice: 12 tensor passes against 8; these shapes are HBM-bound).
 // SQP / SKP = padded row counts (multiples of 32) the LDS image is sized for.
 // ---------------------------------------------------------------------------------------------------------------------
-// RSPLIT: the two roles run on SEPARATE waves of a larger workgroup (SQP / 32 waves for dQ, SKP / 32 more for dK / dV) instead
-// of one after the other on the same waves: the dependent MFMA chain of a workgroup is half as long and no wave carries both
-// roles' accumulators (small buckets only: the LDS image is the single-phase one).
-template <int HD, int SQP, int SKP, bool RSPLIT = false>
-__global__ __launch_bounds__(RSPLIT ? (SQP + SKP) * 2 : (SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_kernel(md_attn_args p) {
+template <int HD, int SQP, int SKP>
+__global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * SQP + 2 * SKP) * PK + 2 * SQP * 4];
     unsigned char* sQ = smem;
@@ -531,7 +421,7 @@ __global__ __launch_bounds__(RSPLIT ? (SQP + SKP) * 2 : (SQP > SKP ? SQP : SKP) 
     // 25-30 us for ~3 us of arithmetic.)  delta = rowsum(dO * O) is formed from the staged registers (dO is read once).
     {
         constexpr int CPR = HD / 8;
-        constexpr int NT = RSPLIT ? (SQP + SKP) * 2 : (SQP > SKP ? SQP : SKP) * 2;                 // = blockDim.x
+        constexpr int NT = (SQP > SKP ? SQP : SKP) * 2;                 // = blockDim.x
         constexpr int ITQ = (SQP * CPR + NT - 1) / NT, ITK = (SKP * CPR + NT - 1) / NT;
         const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
         u32x4 rq[ITQ], rdo[ITQ], ro[ITQ], rk[ITK], rv[ITK];
@@ -633,12 +523,11 @@ __global__ __launch_bounds__(RSPLIT ? (SQP + SKP) * 2 : (SQP > SKP ? SQP : SKP) 
             store_rows<HD>(dQ, dqacc, 1.f, lane);
         }
     }
-    // ---------------- role 2: dK, dV for key rows kw * 32 ..   (RSPLIT: the waves behind the SQP / 32 query-row waves)
-    const int kw = RSPLIT ? wave - SQP / 32 : wave;
-    if (kw >= 0 && kw < nk32) {
-        const unsigned char* myK = sK + kw * 32 * PK;
-        const unsigned char* myV = sV + kw * 32 * PK;
-        const int64_t key = (int64_t)kw * 32 + (lane & 31);
+    // ---------------- role 2: dK, dV for key rows wave * 32 ..
+    if (wave < nk32) {
+        const unsigned char* myK = sK + wave * 32 * PK;
+        const unsigned char* myV = sV + wave * 32 * PK;
+        const int64_t key = (int64_t)wave * 32 + (lane & 31);
         bf16x8 kf[HD / 16], vf[HD / 16];
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
@@ -1006,15 +895,12 @@ template <int HD>
 bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
     if (!bq || !bk) return false;
-    if (variant == 5 && (bq > 96 || bk > 96)) return false;     // roles on separate waves: the small buckets only
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-#define FUSEDR(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP, true>), grid, dim3((SQP + SKP) * 2), 0, stream, *a)
 #define FUSED2(SQP, SKP, SPL) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
 #define SMALL(SQP, SKP)                          \
     do {                                         \
-        if (variant == 5) FUSEDR(SQP, SKP);      \
-        else if (variant == 2 || (variant == 0 && SQP == 64 && SKP == 64)) FUSED(SQP, SKP); \
+        if (variant == 2 || (variant == 0 && SQP == 64 && SKP == 64)) FUSED(SQP, SKP); \
         else if (variant == 4) FUSED2(SQP, SKP, true); \
         else FUSED2(SQP, SKP, false);            \
     } while (0)
@@ -1035,7 +921,6 @@ bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
 #undef SMALL
 #undef BIG
 #undef FUSED
-#undef FUSEDR
 #undef FUSED2
     return true;
 }
@@ -1055,27 +940,8 @@ inline bool attn_ok(const md_attn_args* a) {
 
 extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a)) return MD_BAD_ARG;
-    if (a->fwd_variant < 0 || a->fwd_variant > 2) return MD_BAD_ARG;
     const int nw = waves_for(a->Sq);
     dim3 grid((unsigned)((a->Sq + 32 * nw - 1) / (32 * nw)), (unsigned)a->H, (unsigned)a->B);
-    // Short key sequences (<= 96 keys: every 64-token self-attention, every cross-attention to the 77 caption tokens): K and V
-    // staged whole behind ONE barrier (attn_fwd_short_kernel).  fwd_variant: 0 = this rule, 1 = the phased kernel, 2 = the short
-    // kernel or -1 when it does not cover the problem (tests, A/B runs).
-    if (a->fwd_variant != 1 && a->Skv <= 96) {
-#define FWDS(HD_, SKP_)                                                                                                   \
-    do {                                                                                                                   \
-        if (nw == 1) hipLaunchKernelGGL((attn_fwd_short_kernel<HD_, SKP_, 64>), grid, dim3(64), 0, stream, *a);            \
-        else if (nw == 2) hipLaunchKernelGGL((attn_fwd_short_kernel<HD_, SKP_, 128>), grid, dim3(128), 0, stream, *a);     \
-        else if (nw == 3) hipLaunchKernelGGL((attn_fwd_short_kernel<HD_, SKP_, 192>), grid, dim3(192), 0, stream, *a);     \
-        else hipLaunchKernelGGL((attn_fwd_short_kernel<HD_, SKP_, 256>), grid, dim3(256), 0, stream, *a);                  \
-    } while (0)
-        if (a->hd == 64) { if (a->Skv <= 64) FWDS(64, 64); else FWDS(64, 96); }
-        else { if (a->Skv <= 64) FWDS(32, 64); else FWDS(32, 96); }
-#undef FWDS
-        MD_LAUNCH_CHECK();
-        return 0;
-    }
-    if (a->fwd_variant == 2) return -1;
     // chunks of a 32-row phase per thread and matrix: 32 * hd / 8 / (64 * nw)
 #define FWD(HD_)                                                                                                  \
     do {                                                                                                           \
@@ -1095,7 +961,7 @@ extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
     // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
-    if (a->bwd_split < 0 || a->bwd_split > 5) return MD_BAD_ARG;
+    if (a->bwd_split < 0 || a->bwd_split > 4) return MD_BAD_ARG;
     if (a->bwd_split != 1) {
         if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
             MD_LAUNCH_CHECK();

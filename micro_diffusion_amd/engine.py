@@ -108,7 +108,6 @@ class DiTEngine:
         self.kernel_profile = None         # bench.py: {class name: [(event0, event1, algorithmic bytes)]} for the bandwidth-bound kernels
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
         self.attn_bwd_prefer = hip.ATTN_BWD_AUTO   # same for the attention backward (md_attn_args.bwd_split)
-        self.attn_fwd_variant = 0          # md_attn_args.fwd_variant (A/B: 1 = the 32-key phased kernel also for short key sequences)
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
         self.before_segment = None         # data parallelism: callable(bucket key) run before the first kernel that reads the bf16
         #                                    weights of a bucket ("rest", block names, "final_layer"): waits for their all-gather
@@ -172,7 +171,6 @@ class DiTEngine:
 
     def _attn_fwd(self, a):
         nb = 2.0 * a.hd * (2 * a.Sq + 2 * a.Skv) * a.B * a.H
-        a.fwd_variant = self.attn_fwd_variant
         self._prof("attention", nb, lambda: hip.check(self.L.md_attn_fwd(byref(a), self._st()), "md_attn_fwd"))
 
     def _gemm(self, **kw):

@@ -31,13 +31,11 @@ for name, B, H, Sq, Skv, packed in shapes:
                      Skv * ld[2], Sq * hid, 1 / math.sqrt(hd), hd, 0)
     st = hip.stream_ptr()
     elt = B * H * hd * 2
-    for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd phased ", 4, -1, elt * (2 * Sq + 2 * Skv)), (L.md_attn_fwd, "fwd short  ", 4, -2, elt * (2 * Sq + 2 * Skv)),
-                                        (L.md_attn_bwd, "bwd auto   ", 10, 0, elt * (4 * Sq + 4 * Skv)),
+    for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd        ", 4, 0, elt * (2 * Sq + 2 * Skv)), (L.md_attn_bwd, "bwd auto   ", 10, 0, elt * (4 * Sq + 4 * Skv)),
                                         (L.md_attn_bwd, "bwd 1-phase", 10, 2, elt * (4 * Sq + 4 * Skv)), (L.md_attn_bwd, "bwd 2-phase", 10, 3, elt * (4 * Sq + 4 * Skv)),
-                                        (L.md_attn_bwd, "bwd 2ph+spl", 10, 4, elt * (4 * Sq + 4 * Skv)), (L.md_attn_bwd, "bwd rolewav", 10, 5, elt * (4 * Sq + 4 * Skv)),
+                                        (L.md_attn_bwd, "bwd 2ph+spl", 10, 4, elt * (4 * Sq + 4 * Skv)),
                                         (L.md_attn_bwd, "bwd pair   ", 10, 1, elt * (4 * Sq + 4 * Skv))):
-        a.bwd_split = max(split, 0)
-        a.fwd_variant = -split if split < 0 else 0      # -1 / -2: md_attn_fwd's phased / short-key kernel
+        a.bwd_split = split
         if fn(byref(a), st) == -1:
             continue                      # a forced form that does not cover this shape
         torch.cuda.synchronize()

@@ -12,6 +12,7 @@
 #   ab[:<args>]                python scripts/ab_step.py <args> (same-process A/B of engine options)
 #   traffic                    the two PMC passes of scripts/pmc_workload.py + scripts/pmc_traffic.py -> gpurun_out/<tag>_gemm_traffic.json
 #   py:<script and args>       python <script and args>
+#   exe:<file.hip and args>    hipcc the standalone HIP program on the box and run it
 #   pmcsq:<M N K akc bkc [mode]>  rocprofv3 SQ counter pass over scripts/pmc_gemm.py for one shape on pp256 (MFMA pipe busy)
 #   dp2gloo[:<bench flags>]    bench.py --gpus 2, both ranks on this GPU over gloo (functional run of the N > 1 path)
 # Colons separate the step name from its argument; spaces inside an argument must be written as '+'.
@@ -53,7 +54,13 @@ for step in "$@"; do
       python scripts/pmc_traffic.py "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" "gpurun_out/${tag}_gemm_traffic.json" 2>&1 | tail -n 8
       find "gpurun_out/pmc_fetch_$tag" "gpurun_out/pmc_write_$tag" -type f -size +1M -delete 2>/dev/null ;;
     py)
-      timeout -k 10 900 python $arg > "$log" 2>&1; tail -n 40 "$log" ;;
+      set -- $arg; log=gpurun_out/${tag}_$(basename "$1" .py).log      # one log per script: two py steps of a call must not share one
+      timeout -k 10 900 python $arg > "$log" 2>&1; tail -n 60 "$log" ;;
+    exe)
+      # a standalone HIP program: arg = "<source.hip> [args]" -- compiled on the box (hipcc, seconds) and run
+      set -- $arg; src=$1; shift; log=gpurun_out/${tag}_$(basename "$src" .hip).log
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$src" -o /tmp/exe_$$ > "$log" 2>&1 && timeout -k 10 600 /tmp/exe_$$ "$@" >> "$log" 2>&1
+      tail -n 80 "$log" ;;
     pmcsq)
       # SQ counter pass (MFMA pipe busy, wait cycles) over scripts/pmc_gemm.py for ONE shape: arg = "M N K akc bkc [mode]"
       set -- $arg; shp="$1x$2x$3_$4$5${6:-b}"
