@@ -11,11 +11,12 @@ Extra keys of the line (the headline fields are unchanged by them):
                  1 warm-up + 2 timed steps each, N = 1 only (--no-other-stages skips them);
   value_mb256    the headline step with the YAML microbatch (256 = the per-rank shape of an 8-GPU run), N = 1 only;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
-                 the committed rocprofv3 PMC passes (profiles/r3_gemm_traffic.json: counters need rocprofv3 around the process,
+                 the committed rocprofv3 PMC passes (profiles/r4_gemm_traffic.json: counters need rocprofv3 around the process,
                  so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
                  the library it was measured on and `traffic` is null when that differs from the running build);
-  roofline_hbm   the three largest bandwidth-bound kernel classes (LayerNorm, attention, QK-LayerNorm): algorithmic bytes /
-                 per-launch HIP-event time against the 8 TB/s HBM3E peak, from the same untimed profiling step;
+  roofline_hbm   the bandwidth-bound kernel classes (attention, LayerNorm, QK-LayerNorm, SwiGLU, gate backward, split-K reduce):
+                 algorithmic bytes / per-launch HIP-event time against the 8 TB/s HBM3E peak AND against the streaming envelope
+                 measured on this chip for the class's read : write mix (scripts/hbm_envelope.hip), from the same profiling step;
   dp             (N > 1) ranks verified by an all-reduce of ones over RCCL, exchange format, buckets, and the time the
                  compute stream waited for the gradient exchange after the last backward kernel (`exposed_comm_ms`);
   cpu_baseline   the CPU restatement of the reference step on the host cores (kind "port": the reference is pure Python and
@@ -61,6 +62,12 @@ def dezero_(dit, seed=1234):
 
 
 HBM_PEAK_TBS = 8.0                  # /opt/skills/guides/MI355X_MICROARCH.md (HBM3E)
+# What the same HBM delivers to STREAMING kernels, measured on this chip with no arithmetic at all (scripts/hbm_envelope.hip,
+# profiles/r4_hbm_envelope.txt: 16-byte accesses, 1 GiB per stream, several loads in flight per lane): the practical ceiling of a
+# bandwidth-bound kernel depends on its read : write mix, so every class below is also reported as a fraction of ITS envelope.
+HBM_ENVELOPE_TBS = {"read_only": 6.26, "write_only": 4.59, "copy_1r_1w": 4.95, "rows_1r_1w": 5.53, "2r_1w": 5.64, "3r_2w": 5.46}
+KERNEL_ENVELOPE = {"layernorm": "rows_1r_1w", "qk_layernorm": "rows_1r_1w", "swiglu": "3r_2w", "gate_bwd": "2r_1w", "splitk_reduce": "read_only",
+                   "attention": "3r_2w"}
 CPU_BASELINE_THREADS_CAP = 32      # torch CPU ops with hundreds of threads on small tensors oversubscribe badly
 CPU_BASELINE_TIMEOUT_S = 300
 CPU_BASELINE_STEPS = 3             # timed steps after one warm-up
@@ -186,19 +193,22 @@ class Stage:
         torch.cuda.empty_cache()
 
 
+TRAFFIC_FILE = "r4_gemm_traffic.json"
+
+
 def gemm_traffic():
     """HBM bytes per GEMM launch of the headline step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate --pmc runs, calibrated on a 1 GiB copy of the same pass; scripts/pmc_workload.py + scripts/pmc_traffic.py write the
     file).  The counters need rocprofv3 around the process, so they are NOT measured by this run; the number is returned only
     when the file was measured on THIS build of the library (source hash stamped into it), else null + `stale`."""
     from micro_diffusion_amd import hip
-    path = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
         return None, {"file": None, "traffic_measured_in_run": False}
     with open(path) as fh:
         t = json.load(fh)
     info = {k: v for k, v in t.items() if k != "per_kernel"}
-    info.update(file="profiles/r3_gemm_traffic.json", traffic_measured_in_run=False, running_build=hip._source_hash(),
+    info.update(file="profiles/" + TRAFFIC_FILE, traffic_measured_in_run=False, running_build=hip._source_hash(),
                 stale=t.get("library_source_hash") != hip._source_hash())
     return (None if info["stale"] else t.get("bytes_per_launch")), info
 
@@ -358,17 +368,27 @@ def main():
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             byt = sum(r[2] for r in recs)
             if ms > 0:
-                hb[name] = {"launches": len(recs), "total_ms": ms, "algorithmic_gb": byt / 1e9, "achieved_tbs": byt / (ms * 1e-3) / 1e12,
-                            "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                tbs = byt / (ms * 1e-3) / 1e12
+                env = KERNEL_ENVELOPE.get(name)
+                hb[name] = {"launches": len(recs), "total_ms": ms, "algorithmic_gb": byt / 1e9, "achieved_tbs": tbs,
+                            "frac_of_hbm_peak": tbs / HBM_PEAK_TBS,
+                            "streaming_envelope": env, "frac_of_streaming_envelope": (tbs / HBM_ENVELOPE_TBS[env]) if env else None,
                             "share_of_step": (ms / ms_per_step) if world == 1 else None}
         eng.kernel_profile = None
         eng = None
-        out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_TBS, "unit": "TB/s", "kernels": dict(sorted(hb.items(), key=lambda kv: -kv[1]["total_ms"]))}
+        out["roofline_hbm"] = {"bound": "hbm", "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                               "streaming_envelope_tbs": HBM_ENVELOPE_TBS,
+                               "streaming_envelope_source": "scripts/hbm_envelope.hip on MI355X, profiles/r4_hbm_envelope.txt (no-arithmetic kernels of the same access shapes)",
+                               "kernels": dict(sorted(hb.items(), key=lambda kv: -kv[1]["total_ms"]))}
     if world == 1 and not args.no_other_stages:
         # ---- the YAML microbatch (the per-rank shape of an 8-GPU run) on the same model
         head.trainer.microbatch_size = 256
         e256, _ = head.timed(2, 1, 1)
         out["value_mb256"] = args.global_batch * 2 / e256
+        # the same headline step at the YAML's device_train_microbatch_size (configs/res_256_pretrain.yaml: 256 = the per-rank
+        # shape of an 8-GPU run): the N = 1 figure an N = 8 scaling ratio has to be read against
+        out["config"]["yaml_microbatch"] = 256
+        out["config"]["value_at_yaml_microbatch"] = out["value_mb256"]
         head.trainer.microbatch_size = args.microbatch
     head.close()
     if world == 1 and not args.no_other_stages:

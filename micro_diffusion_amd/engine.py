@@ -517,7 +517,7 @@ class DiTEngine:
                 self.lin_fwd(t.xm3, n + ".mlp.w1", t.h12, M, f, d, ldc=2 * f)
                 self.lin_fwd(t.xm3, n + ".mlp.w2", t.h12, M, f, d, ldc=2 * f, ooff=f)
             t.a = self.empty(M, f)
-            hip.check(L.md_swiglu_fwd(t.h12.data_ptr(), 2 * f, t.a.data_ptr(), f, M, f, st), "swiglu")
+            self._prof("swiglu", 6.0 * M * f, lambda: hip.check(L.md_swiglu_fwd(t.h12.data_ptr(), 2 * f, t.a.data_ptr(), f, M, f, st), "swiglu"))
             self.lin_fwd(t.a, n + ".mlp.w3", x3, M, d, f, mode=hip.EPI_RESIDUAL, res=x2, gate=gate_mlp, ldg=6 * d, rps=S,
                          C2=t.br3)
         else:
@@ -579,15 +579,15 @@ class DiTEngine:
         rpb = self._rows_per_block(M, S)
         # ---------------- feed-forward branch
         dbr3 = self.empty(M, d)
-        hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, 6 * d, dbr3.data_ptr(), dmp + 4 * 5 * d, 6 * d,
-                                M, d, S, rpb, st), "gate_bwd")
+        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, 6 * d, dbr3.data_ptr(),
+                                                                          dmp + 4 * 5 * d, 6 * d, M, d, S, rpb, st), "gate_bwd"))
         dxm3 = self.empty(M, d)
         if not bp.moe:
             self.lin_wgrad(dbr3, t.a, n + ".mlp.w3", M, d, f, defer=True)
             da = self.empty(M, f)
             self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
             dh12 = self.empty(M, 2 * f)
-            hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd")
+            self._prof("swiglu", 10.0 * M * f, lambda: hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd"))
             if self._fused12(n + ".mlp"):
                 self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, 2 * f, d, defer=True)
                 self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, 2 * f, d)
@@ -658,8 +658,8 @@ class DiTEngine:
         self.ln_bwd(a2, dxn2, dx, accumulate=True, wname=n + ".norm2")
         # ---------------- self-attention branch
         dbr1 = self.empty(M, d)
-        hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, 6 * d, dbr1.data_ptr(), dmp + 4 * 2 * d, 6 * d,
-                                M, d, S, rpb, st), "gate_bwd")
+        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, 6 * d, dbr1.data_ptr(),
+                                                                          dmp + 4 * 2 * d, 6 * d, M, d, S, rpb, st), "gate_bwd"))
         self.lin_wgrad(dbr1, t.sa.o, n + ".attn.proj", M, d, h, defer=True)
         do = self.empty(M, h)
         self.lin_dgrad(dbr1, n + ".attn.proj", do, M, d, h)
@@ -885,7 +885,7 @@ class DiTEngine:
             self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w1", cb.h12, Mc, fc, D, ldc=2 * fc)
             self.lin_fwd(cb.xn2, "y_emb_preprocess.mlp.w2", cb.h12, Mc, fc, D, ldc=2 * fc, ooff=fc)
         cb.a = self.empty(Mc, fc)
-        hip.check(L.md_swiglu_fwd(cb.h12.data_ptr(), 2 * fc, cb.a.data_ptr(), fc, Mc, fc, st), "swiglu")
+        self._prof("swiglu", 6.0 * Mc * fc, lambda: hip.check(L.md_swiglu_fwd(cb.h12.data_ptr(), 2 * fc, cb.a.data_ptr(), fc, Mc, fc, st), "swiglu"))
         y2 = self.empty(Mc, D)
         self.lin_fwd(cb.a, "y_emb_preprocess.mlp.w3", y2, Mc, D, fc, mode=hip.EPI_RESIDUAL, res=y1)
         tp.cb, tp.y2 = cb, y2
@@ -1120,7 +1120,7 @@ class DiTEngine:
         da = self.empty(Mc, fc)
         self.lin_dgrad(dy, "y_emb_preprocess.mlp.w3", da, Mc, D, fc)
         dh12 = self.empty(Mc, 2 * fc)
-        hip.check(L.md_swiglu_bwd(da.data_ptr(), fc, cb.h12.data_ptr(), 2 * fc, dh12.data_ptr(), 2 * fc, Mc, fc, st), "swiglu_bwd")
+        self._prof("swiglu", 10.0 * Mc * fc, lambda: hip.check(L.md_swiglu_bwd(da.data_ptr(), fc, cb.h12.data_ptr(), 2 * fc, dh12.data_ptr(), 2 * fc, Mc, fc, st), "swiglu_bwd"))
         dxn2 = self.empty(Mc, D)
         if self._fused12("y_emb_preprocess.mlp"):
             self.lin_wgrad(dh12, cb.xn2, "y_emb_preprocess.mlp.w1", Mc, 2 * fc, D)

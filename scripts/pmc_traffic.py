@@ -1,4 +1,4 @@
-"""Turn the two rocprofv3 --pmc passes of scripts/pmc_workload.py into profiles/r3_gemm_traffic.json (bench.py reads it for
+"""Turn the two rocprofv3 --pmc passes of scripts/pmc_workload.py into profiles/r4_gemm_traffic.json (bench.py reads it for
 roofline.traffic and compares the `library_source_hash` stamped here with the build it runs: a stale file yields traffic null).  FETCH_SIZE / WRITE_SIZE are calibrated on the known-size copy launches of the same run (the guide's
 gfx950 note: FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads; WRITE_SIZE is uncalibrated): the factor
 that maps the counter to 2^30 bytes on the copy kernel is applied to the GEMM launches.
@@ -32,7 +32,7 @@ def load(d, counter):
 
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
-    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3_gemm_traffic.json")
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r4_gemm_traffic.json")
     fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 
     def copy_kernel(per):

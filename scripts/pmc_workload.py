@@ -3,7 +3,7 @@ elementwise copy, 16-byte accesses: 1 GiB read + 1 GiB written per launch) follo
 MicroDiT-XL/2 microbatch (the GEMM launches of the headline step).  Run once per counter:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python scripts/pmc_workload.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python scripts/pmc_workload.py
-then scripts/pmc_traffic.py turns the two CSVs into profiles/r3_gemm_traffic.json (stamped with the library's source hash)."""
+then scripts/pmc_traffic.py turns the two CSVs into profiles/r4_gemm_traffic.json (stamped with the library's source hash)."""
 import os
 import sys
 
