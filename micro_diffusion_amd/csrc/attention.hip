@@ -89,6 +89,41 @@ __device__ __forceinline__ void stage_pair(unsigned char* tileA, unsigned char* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Softmax arithmetic of the backward kernels.  At S = 256 these kernels are VALU-bound, not MFMA- or HBM-bound (round 4: with
+// the tile loops emptied the 256 x 256 backward runs 2.2x faster, the 64-row shapes 1.04x): per score element the first version
+// spent ~12 instructions -- a 64-bit index compare + select for the sequence mask on EVERY tile, scale, subtract, exp through
+// a multiply, two more multiplies for dS -- next to ~1.5 MFMA cycles.  Now: ONE fma + v_exp_f32 (scores go to the log2 domain
+// with c1 = scale * log2(e) and the saved log-sum-exp pre-multiplied by log2(e)), dS without the softmax scale (it is applied
+// once, to the dQ / dK accumulators at the store), and the mask only on a ragged last tile (`rem` = rows / keys left, wave-uniform).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ int tile_slot(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }   // row / key of accumulator register r
+
+// (The mask is a per-element compare + select against the wave-uniform `rem`, and the exponent is formed as s * c1 - l2, not as a
+// fused multiply-add inside a branch on `rem < 32`: the branchy / fma forms cost 8-12 more VGPRs in every kernel here and pushed
+// the capped two-phase kernels into scratch.)
+// lane <-> query (l2, dlt belong to this lane), registers <-> the tile's 32 keys:  s <- dS^T / scale = P^T (dP^T - delta)
+__device__ __forceinline__ void ds_cols(f32x16& s, const f32x16& dp, float c1, float l2, float dlt, int rem, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pr = tile_slot(r, hh) < rem ? __builtin_amdgcn_exp2f(s[r] * c1 - l2) : 0.f;
+        s[r] = pr * (dp[r] - dlt);
+    }
+}
+// lane <-> key, registers <-> the tile's 32 query rows (tL2 / tDlt: their log2-domain log-sum-exp / delta in LDS):
+// s <- P,  dp <- dS / scale = P (dP - delta)      (WANT_P / WANT_DS select the outputs a pass needs)
+template <bool WANT_P, bool WANT_DS>
+__device__ __forceinline__ void p_ds_rows(f32x16& s, f32x16& dp, float c1, const float* tL2, const float* tDlt, int rem, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ql = tile_slot(r, hh);
+        const float pr = ql < rem ? __builtin_amdgcn_exp2f(s[r] * c1 - tL2[ql]) : 0.f;
+        if (WANT_DS) dp[r] = pr * (dp[r] - tDlt[ql]);
+        if (WANT_P) s[r] = pr;
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
     bf16x8 o;
 #pragma unroll
@@ -120,6 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
     const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool qvalid = q < p.Sq;
@@ -158,21 +194,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s)
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+        // online softmax in the log2 domain (m, m_new, the scores: all x log2 e): one multiply + v_exp_f32 per element, a 32-bit
+        // compare + select for the key mask (the first version: a 64-bit index compare per element and exp through __expf)
+        const int rem = (int)(p.Skv - key0);
         float tmax = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float v = key < p.Skv ? sacc[r] * p.scale : -1e30f;
-            sacc[r] = v;
-            tmax = fmaxf(tmax, v);
+            sacc[r] = tile_slot(r, hh) < rem ? sacc[r] * c1 : -1e30f;
+            tmax = fmaxf(tmax, sacc[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m, tmax);
-        const float alpha = __expf(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pr = __expf(sacc[r] - m_new);
+            const float pr = __builtin_amdgcn_exp2f(sacc[r] - m_new);
             sacc[r] = pr;
             psum += pr;
         }
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     if (qvalid) {
         bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
         store_rows<HD>(O, oacc, 1.f / l, lane);
-        if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = m + __logf(l);
+        if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = (m + __log2f(l)) * 0.6931471805599453f;   // natural log
     }
 }
 
@@ -228,7 +265,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
             }
         }
     }
-    const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] : 0.f;
+    const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] * LOG2E : 0.f;   // log2 domain (ds_cols)
+    const float c1 = p.scale * LOG2E;
     // delta[q] = sum_d dO[q, d] * O[q, d]: this lane holds half of row q (its 8-wide d-chunks), the partner lane the rest
     float dlt = 0.f;
     if (qvalid) {
@@ -268,12 +306,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
             dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
-            sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
-        }
+        ds_cols(sacc, dpacc, c1, lse, dlt, (int)(p.Skv - key0), hh);   // dS^T / scale
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             const bf16x8 dsf = pack8(sacc, 8 * sp);
@@ -286,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
     }
     if (qvalid) {
         bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-        store_rows<HD>(dQ, dqacc, 1.f, lane);
+        store_rows<HD>(dQ, dqacc, p.scale, lane);
     }
 }
 
@@ -298,6 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
     float* sDltAll = sLseAll + STG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
     const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t key = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool kvalid = key < p.Skv;
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
         stage_pair<HD, STG * (HD / 8) / 64>(smem, smem + STG * PK, PK, Q, p.ldq, dO, p.lddo, qbase, p.Sq, nst, tid, nthreads);
         for (int i = tid; i < nst; i += nthreads) {
             const bool v = qbase + i < p.Sq;
-            sLseAll[i] = v ? LSE[qbase + i] : 0.f;
+            sLseAll[i] = v ? LSE[qbase + i] * LOG2E : 0.f;       // log2 domain (p_ds_rows)
             sDltAll[i] = v ? DLT[qbase + i] : 0.f;
         }
         __syncthreads();
@@ -358,13 +392,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
             dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float pr = (q0 + ql < p.Sq) ? __expf(sacc[r] * p.scale - sLse[ql]) : 0.f;
-            sacc[r] = pr;                                           // P
-            dpacc[r] = pr * (dpacc[r] - sDlt[ql]) * p.scale;        // dS
-        }
+        p_ds_rows<true, true>(sacc, dpacc, c1, sLse, sDlt, (int)(p.Sq - q0), hh);   // P, dS / scale
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             const bf16x8 pf = pack8(sacc, 8 * sp);
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
     if (kvalid) {
         bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
         bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
-        store_rows<HD>(dK, dkacc, 1.f, lane);
+        store_rows<HD>(dK, dkacc, p.scale, lane);
         store_rows<HD>(dV, dvacc, 1.f, lane);
     }
 }
@@ -407,6 +435,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
     float* sDlt = sLse + SQP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
     const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
     const int64_t b = blockIdx.y, h = blockIdx.x;
     const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
     const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
@@ -458,7 +487,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
             for (int s2 = CPR / 2; s2 > 0; s2 >>= 1) d += __shfl_xor(d, s2, 64);      // the CPR lanes of a row are adjacent (NT % CPR == 0)
             if (c == 0 && task < SQP * CPR) {
                 sDlt[r] = d;
-                sLse[r] = rl[it];
+                sLse[r] = rl[it] * LOG2E;          // log2 domain (ds_cols / p_ds_rows)
             }
         }
 #pragma unroll
@@ -503,12 +532,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t key = (int64_t)j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
-                sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
-            }
+            ds_cols(sacc, dpacc, c1, lse, dlt, (int)p.Skv - j * 32, hh);   // dS^T / scale
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 dsf = pack8(sacc, 8 * sp);
@@ -520,7 +544,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
         }
         if (q < p.Sq) {
             bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-            store_rows<HD>(dQ, dqacc, 1.f, lane);
+            store_rows<HD>(dQ, dqacc, p.scale, lane);
         }
     }
     // ---------------- role 2: dK, dV for key rows wave * 32 ..
@@ -558,13 +582,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
-                sacc[r] = pr;                                           // P
-                dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
-            }
+            p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, (int)p.Sq - i * 32, hh);   // P, dS / scale
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 pf = pack8(sacc, 8 * sp);
@@ -581,7 +599,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
         if (key < p.Skv) {
             bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
             bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
-            store_rows<HD>(dK, dkacc, 1.f, lane);
+            store_rows<HD>(dK, dkacc, p.scale, lane);
             store_rows<HD>(dV, dvacc, 1.f, lane);
         }
     }
@@ -617,6 +635,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
     float* sDlt = sLse + SQP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
     const int64_t b = blockIdx.y, h = blockIdx.x;
     const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
     const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
@@ -666,7 +685,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
             for (int s2 = CPR / 2; s2 > 0; s2 >>= 1) d += __shfl_xor(d, s2, 64);      // the CPR lanes of a row are adjacent (NT % CPR == 0)
             if (c == 0 && task < SQP * CPR) {
                 sDlt[r] = d;
-                sLse[r] = rl[it];
+                sLse[r] = rl[it] * LOG2E;          // log2 domain (ds_cols / p_ds_rows)
             }
         }
     }
@@ -717,12 +736,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t key = (int64_t)j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pr = key < p.Skv ? __expf(sacc[r] * p.scale - lse) : 0.f;
-                sacc[r] = pr * (dpacc[r] - dlt) * p.scale;  // dS^T
-            }
+            ds_cols(sacc, dpacc, c1, lse, dlt, (int)p.Skv - j * 32, hh);   // dS^T / scale
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 dsf = pack8(sacc, 8 * sp);
@@ -734,7 +748,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
         }
         if (q < p.Sq) {
             bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-            store_rows<HD>(dQ, dqacc, 1.f, lane);
+            store_rows<HD>(dQ, dqacc, p.scale, lane);
         }
     }
     // this wave's 32 key rows, while K and V are still in LDS
@@ -778,11 +792,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
 #pragma unroll
                 for (int s = 0; s < HD / 16; ++s)
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    sacc[r] = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;   // P
-                }
+                p_ds_rows<true, false>(sacc, sacc, c1, tLse, nullptr, (int)p.Sq - i * 32, hh);   // P
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     const bf16x8 pf = pack8(sacc, 8 * sp);
@@ -814,12 +824,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
                     dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
-                    dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
-                }
+                p_ds_rows<false, true>(sacc, dpacc, c1, tLse, tDlt, (int)p.Sq - i * 32, hh);   // dS / scale
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     const bf16x8 dsf = pack8(dpacc, 8 * sp);
@@ -829,7 +834,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                             tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, acc[di], 0, 0, 0);
                 }
             }
-            if (key < p.Skv) store_rows<HD>(dK, acc, 1.f, lane);
+            if (key < p.Skv) store_rows<HD>(dK, acc, p.scale, lane);
         } else {
             f32x16 dkacc[HD / 32], dvacc[HD / 32];
 #pragma unroll
@@ -855,13 +860,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
                     dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float pr = ((int64_t)i * 32 + ql < p.Sq) ? __expf(sacc[r] * p.scale - tLse[ql]) : 0.f;
-                    sacc[r] = pr;                                           // P
-                    dpacc[r] = pr * (dpacc[r] - tDlt[ql]) * p.scale;        // dS
-                }
+                p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, (int)p.Sq - i * 32, hh);   // P, dS / scale
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     const bf16x8 pf = pack8(sacc, 8 * sp);
@@ -876,7 +875,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                 }
             }
             if (key < p.Skv) {
-                store_rows<HD>(dK, dkacc, 1.f, lane);
+                store_rows<HD>(dK, dkacc, p.scale, lane);
                 store_rows<HD>(dV, dvacc, 1.f, lane);
             }
         }
