@@ -367,3 +367,29 @@ def test_grouped_wgrad_host_logic():
     assert all(stride == span and k_ == ks and acc == 1 for _, _, _, stride, k_, acc in calls["reduce"])
     assert calls["reduce"][1][0] - calls["reduce"][0][0] == eng.G["xproj.weight"].data_ptr() - base     # slice offsets mirror the gradient layout
     assert eng._wgroup == [] and not eng._wgrad_flush()                    # an empty group flushes to nothing
+
+
+def test_rccl_channel_cap_and_in_flight_host_logic(monkeypatch):
+    """trainer.cap_rccl_channels / rccl_channel_cap (NCCL_MAX_NCHANNELS: set once before the communicator exists, an exported value wins)
+    and GradSync.in_flight() (what switches md_gemm_args.cu_limit on): host logic only."""
+    from micro_diffusion_amd import trainer as tr
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS", raising=False)
+    assert tr.rccl_channel_cap() == 0                        # unknown: the Trainer then leaves the GEMM grids alone
+    assert tr.cap_rccl_channels() == tr.RCCL_CHANNELS_DEFAULT == 8
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and os.environ["NCCL_MIN_NCHANNELS"] == "8"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "4")
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS", raising=False)
+    assert tr.cap_rccl_channels(16) == 4 and os.environ["NCCL_MIN_NCHANNELS"] == "4"     # the user's cap wins, MIN never exceeds it
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "not-a-number")
+    assert tr.rccl_channel_cap() == 0
+    sync = tr.GradSync(_FakeDiT(0))                          # no process group: a single rank, nothing in flight
+    assert not sync.enabled and not sync.in_flight()
+    sync.pending.append(object())
+    assert sync.in_flight()
+    sync.pending.clear()
+    sync.gather_work["blocks.0"] = [object()]
+    assert sync.in_flight()
+    sync.wait_gather = lambda key=None: sync.gather_work.clear()
+    sync.wait_gather()
+    assert not sync.in_flight()
