@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--microbatch", type=int, default=1024)
     ap.add_argument("--bench-value", type=float, default=None, help="bench.py's images/sec of the same build, for the ratio")
+    ap.add_argument("--override", action="append", default=[], help="extra train.py overrides (key=value), e.g. scheduler.t_warmup=10ba")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_py_loader.json"))
     a = ap.parse_args()
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
@@ -36,7 +37,7 @@ def main():
         t_write = time.time() - t0
         cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--config-path", os.path.join(ROOT, "configs"), "--config-name", "res_256_pretrain",
                f"dataset.train.datadir=[{d}]", f"trainer.max_duration={a.steps}ba", f"trainer.device_train_microbatch_size={a.microbatch}",
-               "trainer.eval_interval=0ba", "trainer.save_interval=0ba", "trainer.save_folder=null", "+misc.log_interval=1"]
+               "trainer.eval_interval=0ba", "trainer.save_interval=0ba", "trainer.save_folder=null", "+misc.log_interval=1"] + list(a.override)
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1500)
         wall = time.time() - t0
@@ -53,6 +54,7 @@ def main():
     per_sample = shard_bytes / a.samples
     out = {"command": " ".join(cmd[1:]).replace(ROOT + "/", ""), "steps": len(logs), "skipped": a.skip,
            "images_per_sec_train_py_loader": mean, "per_step": [l["samples_per_sec"] for l in logs], "loss_last": logs[-1]["loss"],
+           "loss_per_step": [l["loss"] for l in logs], "lr_per_step": [l["lr"] for l in logs],
            "shard_bytes_per_sample": per_sample, "host_to_device_gb_per_sec": mean * per_sample / 1e9,
            "samples_in_shards": a.samples, "shard_write_s": t_write, "wall_s": wall,
            "bench_py_images_per_sec": a.bench_value, "ratio_to_bench_py": (mean / a.bench_value) if a.bench_value else None,
