@@ -8,8 +8,11 @@ exchange (N > 1), clip, AdamW.  Prints ONE JSON line (contract in the task descr
 Extra keys of the line (the headline fields are unchanged by them):
   other_stages   the same full step on the reference's other stage configs (BASELINE.json configs[3], [4]):
                  res_256_finetune (mask 0: 256 backbone tokens) and res_512_pretrain (64x64 latents, pos_interp_scale 2),
-                 1 warm-up + 2 timed steps each, N = 1 only (--no-other-stages skips them);
+                 1 warm-up + 5 timed steps each at microbatch 256 (their YAMLs say 64 / 32: stated per stage), N = 1 only
+                 (--no-other-stages skips them);
   value_mb256    the headline step with the YAML microbatch (256 = the per-rank shape of an 8-GPU run), N = 1 only;
+  value_mb256_cu248, n8_ceiling   the same with every persistent-GEMM grid limited to the 248 CUs an 8-channel RCCL kernel leaves
+                 (the rank-of-8 step emulated on one GPU) and 8 x that / the headline; `_whole_tiles` = without the split-K tail;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
                  the committed rocprofv3 PMC passes (profiles/r4_gemm_traffic.json: counters need rocprofv3 around the process,
                  so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
@@ -41,12 +44,12 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md 
 # HBM-sized default per stage (the YAML values 256 / 64 / 32 are 80 GB-H100 settings; any split accumulates the same gradient).
 STAGES = {
     "res_256_pretrain": dict(latent_res=32, pos_interp_scale=1.0, mask=0.75, p_mean=-0.6, p_std=1.2, lr=2.4e-4, clip=0.25,
-                             microbatch=1024, key=("res256", 0.75),
+                             microbatch=1024, yaml_microbatch=256, key=("res256", 0.75),
                              sched=("cosine_with_warmup", dict(t_warmup="2500ba", t_max="250000ba", alpha_f=0.33))),
     "res_256_finetune": dict(latent_res=32, pos_interp_scale=1.0, mask=0.0, p_mean=-0.6, p_std=1.2, lr=8e-5, clip=0.25,
-                             microbatch=256, key=("res256", 0.0), sched=("constant", dict(alpha=1.0))),
+                             microbatch=256, yaml_microbatch=64, key=("res256", 0.0), sched=("constant", dict(alpha=1.0))),
     "res_512_pretrain": dict(latent_res=64, pos_interp_scale=2.0, mask=0.75, p_mean=0.0, p_std=0.6, lr=8e-5, clip=0.5,
-                             microbatch=256, key=("res512", 0.75), sched=("constant_with_warmup", dict(t_warmup="500ba", alpha=1.0))),
+                             microbatch=256, yaml_microbatch=32, key=("res512", 0.75), sched=("constant_with_warmup", dict(t_warmup="500ba", alpha=1.0))),
 }
 
 
@@ -68,6 +71,7 @@ HBM_PEAK_TBS = 8.0                  # /opt/skills/guides/MI355X_MICROARCH.md (HB
 HBM_ENVELOPE_TBS = {"read_only": 6.26, "write_only": 4.59, "copy_1r_1w": 4.95, "rows_1r_1w": 5.53, "2r_1w": 5.64, "3r_2w": 5.46}
 KERNEL_ENVELOPE = {"layernorm": "rows_1r_1w", "qk_layernorm": "rows_1r_1w", "swiglu": "3r_2w", "gate_bwd": "2r_1w", "splitk_reduce": "read_only",
                    "attention": "3r_2w"}
+OTHER_STAGE_STEPS = 5              # timed steps of the res_256_finetune / res_512_pretrain legs (after one warm-up)
 CPU_BASELINE_THREADS_CAP = 32      # torch CPU ops with hundreds of threads on small tensors oversubscribe badly
 CPU_BASELINE_TIMEOUT_S = 300
 CPU_BASELINE_STEPS = 3             # timed steps after one warm-up
@@ -389,16 +393,37 @@ def main():
         # shape of an 8-GPU run): the N = 1 figure an N = 8 scaling ratio has to be read against
         out["config"]["yaml_microbatch"] = 256
         out["config"]["value_at_yaml_microbatch"] = out["value_mb256"]
+        # ---- the rank-of-8 step emulated on ONE GPU: the same 256-image microbatches with every persistent-GEMM
+        # grid limited to the 248 CUs an 8-channel RCCL kernel leaves (what trainer.py does to a rank while a collective is in
+        # flight: at N = 8 that is nearly the whole step).  n8_ceiling = 8 x that rate / the headline: the scaling an 8-GPU run can
+        # reach before a single exposed byte.  `_whole_tiles` = the same with the split-K tail form of the GEMM switched off
+        # (256 tiles on 248 workgroups = two rounds): what the tail form buys.
+        eng = head.model.dit.engine
+        saved_fn, saved_tail = eng.cu_limit_fn, eng.gemm_tail_mode
+        eng.cu_limit_fn = lambda: 248
+        e248, _ = head.timed(2, 1, 1)
+        out["value_mb256_cu248"] = args.global_batch * 2 / e248
+        eng.gemm_tail_mode = 1
+        e248w, _ = head.timed(2, 1, 1)
+        out["value_mb256_cu248_whole_tiles"] = args.global_batch * 2 / e248w
+        eng.cu_limit_fn, eng.gemm_tail_mode = saved_fn, saved_tail
+        eng = None
+        out["n8_ceiling"] = 8.0 * out["value_mb256_cu248"] / value
+        out["n8_ceiling_note"] = ("8 x value_mb256_cu248 / value: 8 ranks each running the 256-image step on 248 CUs, against the 1-GPU "
+                                  "headline (microbatch %d); against value_mb256 the same ratio is %.2f" %
+                                  (args.microbatch, 8.0 * out["value_mb256_cu248"] / out["value_mb256"]))
         head.trainer.microbatch_size = args.microbatch
     head.close()
     if world == 1 and not args.no_other_stages:
         other = {}
         for name in ("res_256_finetune", "res_512_pretrain"):
             st = Stage(name, args.arch, args.global_batch, STAGES[name]["microbatch"], 1, 0)
-            e, l = st.timed(2, 1, 1)
-            v = args.global_batch * 2 / e
-            other[name] = {"value": v, "unit": "images/sec", "ms_per_step": e / 2 * 1e3, "steps": 2, "warmup": 1,
-                           "microbatch": st.microbatch, "loss": l, "gflop_per_image": FWD_BWD_GFLOP_PER_IMG[STAGES[name]["key"]],
+            e, l = st.timed(OTHER_STAGE_STEPS, 1, 1)
+            v = args.global_batch * OTHER_STAGE_STEPS / e
+            other[name] = {"value": v, "unit": "images/sec", "ms_per_step": e / OTHER_STAGE_STEPS * 1e3, "steps": OTHER_STAGE_STEPS, "warmup": 1,
+                           "microbatch": st.microbatch, "yaml_microbatch": STAGES[name]["yaml_microbatch"],
+                           "microbatch_note": "the YAML's device_train_microbatch_size is an 80 GB setting; gradient accumulation is split-invariant",
+                           "loss": l, "gflop_per_image": FWD_BWD_GFLOP_PER_IMG[STAGES[name]["key"]],
                            "step_mfma_frac": v * FWD_BWD_GFLOP_PER_IMG[STAGES[name]["key"]] / 1e3 / MFMA_BF16_DENSE_PEAK_TFLOPS}
             st.close()
         out["other_stages"] = other

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MD_COMM_ABI_VERSION 1
+#define MD_COMM_ABI_VERSION 2
 #define MD_COMM_UNIQUE_ID_BYTES 128
 #define MD_COMM_BAD_ARG (-1)
 #define MD_COMM_NO_RCCL (-2)
@@ -54,6 +54,9 @@ int md_comm_all_gather_bucket(md_comm* c, const void* send, void* recv, int64_t 
 /* `stream` waits (on the device) for the collective that returned `ticket`; ticket <= 0 is a no-op.  Tickets are valid for the
  * MD_COMM_TICKETS (1024) most recent collectives of the communicator. */
 int md_comm_wait(md_comm* c, int64_t ticket, md_comm_stream stream);
+/* 1 = the collective that returned `ticket` has finished on the device, 0 = not yet (host-side poll, never blocks); < 0 = error.
+ * The step uses it to hand RCCL's CUs back to the GEMM grids as soon as the wire is idle (trainer.GradSync.in_flight). */
+int md_comm_query(md_comm* c, int64_t ticket);
 /* The host blocks until every collective issued so far has finished (tests, shutdown). */
 int md_comm_synchronize(md_comm* c);
 

@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MD_ABI_VERSION 4
+#define MD_ABI_VERSION 5
 int md_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM */
@@ -106,6 +106,17 @@ typedef struct md_gemm_args {
      * only when another workgroup has finished its whole tile list -- the launch takes up to twice as long; with the smaller grid
      * the same tiles are dealt to the CUs that are free (ceil(tiles / (256 - k)) rounds). */
     int32_t cu_limit;
+    /* PP256 only, bf16-output epilogues (STORE_BF16 +- GELU, RESIDUAL, DACT): "whole rounds + split-K tail".  When the work items
+     * of a launch do not make whole rounds of its G workgroups (256 tiles on the 248 CUs RCCL leaves: one round + 8 tiles, i.e.
+     * TWO rounds), the r left-over tiles are cut along K into s units each (r * s <= G); workgroup u runs unit u after its own
+     * whole tiles, in the same k-tile stream, and writes its 256 x 256 fp32 partial to tail_ws + u * 256 KiB; a second, small
+     * launch sums the s partials of every left-over tile and applies the launch's epilogue.  The caller provides the workspace
+     * (tail_ws_bytes >= 256 KiB * 256 covers every case; NULL = the form is never used).  tail_mode: 0 = the library decides
+     * (only when its cost model predicts a gain), 1 = never, 2 = whenever it is structurally possible (tests, A/B runs). */
+    void* tail_ws;
+    int64_t tail_ws_bytes;
+    int32_t tail_mode;
+    int32_t* tail_used; /* optional HOST pointer: receives units per left-over tile (s) when the tail form was launched, else 0 */
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot
@@ -286,6 +297,11 @@ int md_edm_heun_update(const double* x_hat, const double* x_in, const float* F, 
 #define MD_SUMSQ_PARTIALS 1024
 int md_sumsq(const void* g, int32_t g_is_bf16, int64_t n, float* partials, hipStream_t stream);
 int md_sumsq_finish(const float* partials, int64_t count, float* out, hipStream_t stream);
+/* Exact integer checksum of n 16-bit words (n % 8 == 0, x 16-byte aligned): out2[0] += sum of the words, out2[1] += sum of
+ * word_i * h(i) with h an odd 32-bit hash of the index; out2 (two uint64 on the device) must be zero on entry.  Order-independent
+ * and exact, so bit-identical on identical data: the replica-consistency check of the data-parallel step compares it across ranks
+ * (a single bf16 ulp, a sign flip or a permutation changes it; no reference counterpart: FSDP keeps one sharded copy). */
+int md_checksum_u16(const void* x, int64_t n, uint64_t* out2, hipStream_t stream);
 /* clip_grad_norm_ (train.py:85-86) + torch.optim.AdamW (train.py:39-43) + bf16 shadow emit (+ EMA of the weights,
  * configs/res_512_*.yaml:4-9), one pass. */
 typedef struct md_adamw_args {

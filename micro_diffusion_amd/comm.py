@@ -23,7 +23,7 @@ CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM
 
 BF16, F32 = 0, 1
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def _source_hash() -> str:
@@ -40,6 +40,8 @@ def build(force: bool = False) -> str:
     With MD_COMM=native all N ranks of a node reach this together: an exclusive file lock serialises them (as hip.build does) and
     the library is linked to a temporary name and renamed into place, so no rank can dlopen a half-written file."""
     import fcntl
+    if not force and _up_to_date():          # nothing to do: no lock file is touched (a read-only install works)
+        return LIB_PATH
     with open(os.path.join(_HERE, ".libmicrodit_comm.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
@@ -48,12 +50,17 @@ def build(force: bool = False) -> str:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _up_to_date() -> bool:
+    if not (os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH)):
+        return False
+    with open(_HASH_PATH) as fh:
+        return fh.read().strip() == _source_hash()
+
+
 def _build_locked(force: bool) -> str:
     want = _source_hash()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH):
-        with open(_HASH_PATH) as fh:
-            if fh.read().strip() == want:
-                return LIB_PATH
+    if not force and _up_to_date():
+        return LIB_PATH
     cxx = os.environ.get("CXX", "g++")
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
     cmd = [cxx, *CXX_FLAGS, "-I", _INCLUDE, "-I", os.path.join(ROCM, "include"), _SRC, "-o", tmp,
@@ -81,6 +88,7 @@ _SIGS = {
     "md_comm_reduce_scatter_bucket": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, POINTER(c_int64)]),
     "md_comm_all_gather_bucket": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, POINTER(c_int64)]),
     "md_comm_wait": (c_int32, [c_void_p, c_int64, c_void_p]),
+    "md_comm_query": (c_int32, [c_void_p, c_int64]),
     "md_comm_synchronize": (c_int32, [c_void_p]),
 }
 
@@ -127,6 +135,13 @@ class Ticket:
     def wait(self) -> None:
         import torch
         check(lib().md_comm_wait(self.comm.handle, self.ticket, torch.cuda.current_stream().cuda_stream), "md_comm_wait")
+
+    def is_completed(self) -> bool:
+        """Host-side poll (torch.distributed's Work.is_completed): has the collective finished on the device?"""
+        r = lib().md_comm_query(self.comm.handle, self.ticket)
+        if r < 0:
+            check(r, "md_comm_query")
+        return r == 1
 
 
 class Comm:

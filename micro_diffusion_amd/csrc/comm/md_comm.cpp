@@ -214,6 +214,18 @@ extern "C" int md_comm_wait(md_comm* c, int64_t ticket, md_comm_stream stream) {
     return 0;
 }
 
+extern "C" int md_comm_query(md_comm* c, int64_t ticket) {
+    if (!c) return MD_COMM_BAD_ARG;
+    if (ticket <= 0) return 1;
+    if (ticket > c->issued) return MD_COMM_BAD_ARG;
+    if (ticket + TICKETS <= c->issued) return 1;         // its event was recycled: 1024 younger collectives have been issued since
+    const hipError_t e = hipEventQuery(c->done[ticket % TICKETS]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    HIP_TRY(e);
+    return 0;
+}
+
 extern "C" int md_comm_synchronize(md_comm* c) {
     if (!c) return MD_COMM_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(c->stream));

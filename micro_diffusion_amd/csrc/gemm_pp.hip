@@ -248,23 +248,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     const int wr = wave >> 2, wc = wave & 3;      // wave group = wr; rows wr * 64 .. of each A half, columns wc * 32 .. of each B half
 
     // ---- this workgroup's share of the work list
+    // Tail form (PPPlan::tail_*; bf16-output epilogues only): the whole tiles are items [0, tail_first); this workgroup's split-K
+    // unit of a left-over tile, if it has one, is its LAST item (ordinal tail_n) -- same k-tile stream, shorter k-loop, raw fp32
+    // tile written in the drain.
+    constexpr bool TAILABLE = EPI != PP_E_F32;
     int w_first, w_stride, w_count;
     {
         const int G = gridDim.x, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int q = w.total >> 3, r = w.total & 7;
+        const int body = (TAILABLE && w.tail_units) ? w.tail_first : w.total;
+        const int q = body >> 3, r = body & 7;
         const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
         const int cnt = q + (x < r ? 1 : 0);
         w_stride = (G - x + 7) >> 3;               // workgroups on this XCD
         w_first = lo + j;
         w_count = j < cnt ? (int)((unsigned)(cnt - j + w_stride - 1) / (unsigned)w_stride) : 0;
     }
-    if (w_count == 0) return;
+    const int tail_n = (TAILABLE && (int)blockIdx.x < w.tail_units) ? w_count : -1;
+    if (w_count == 0 && tail_n < 0) return;
     // Optional timeline (md_gemm_args.timeline, scripts/gemm_pp_timeline.py): 16 int64 per workgroup —
     // [0] clock at entry  [1] wall clock at entry  [2] first k-tile landed  [3 + n] tile n's k-loop done (n < 8)
     // [11] clock at exit  [12] wall clock at exit  [13] XCC_ID << 32 | HW_ID
     long long* const tl = p.timeline ? static_cast<long long*>(p.timeline) + (size_t)blockIdx.x * 16 : nullptr;
     if (tl && tid == 0) { tl[0] = clock64(); tl[1] = wall_clock64(); }
-    const int half_iters = w_count * (w.nk >> 1);  // loop iterations: two k-tiles each
+    const int half_iters = w_count * (w.nk >> 1) + (tail_n >= 0 ? (w.tail_nk >> 1) : 0);  // loop iterations: two k-tiles each
 
     // ---- per-lane constants
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
@@ -306,7 +312,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             sB = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(pr.B) + kb * pr.ldb + n0);
             return;
         }
-        work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
+        int item = w_first + n * w_stride, ksub = 0;
+        if (TAILABLE && n == tail_n) {             // this workgroup's split-K unit of a left-over tile
+            const unsigned u = blockIdx.x, t = u / (unsigned)w.tail_split;
+            item = w.tail_first + (int)t;
+            ksub = (int)(u - t * (unsigned)w.tail_split) * w.tail_nk * BKT;
+        }
+        work_decode(w, item, m0, n0, batch, split);
         stage_offsets<AKC>(aofs, m0, w.M, w.lda, wave, lane);
         stage_offsets<BKC>(bofs, n0, w.N, w.ldb, wave, lane);
         if (EPI == PP_E_F32 && p.A_list) {         // operand lists (fp32-slice kernels only: the others are at their register budget)
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             stager_segment(s_li);
             return;
         }
-        const int64_t kbeg = (int64_t)split * w.kspan;
+        const int64_t kbeg = (int64_t)split * w.kspan + ksub;
         const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
         const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
         sA = reinterpret_cast<const char*>(AKC ? Ab + (int64_t)m0 * w.lda + kbeg : Ab + kbeg * w.lda + m0);
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     auto stager_advance = [&]() {                  // after the last half-tile (A1) of a k-tile
         sA += a_kstep;
         sB += b_kstep;
-        if (++s_kt == w.nk) {
+        if (++s_kt == ((TAILABLE && s_n == tail_n) ? w.tail_nk : w.nk)) {
             s_kt = 0;
             if (++s_n < w_count) stager_open(s_n);
             else s_live = false;
@@ -466,7 +478,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     } while (0)
 
     for (int it = 0; it < half_iters; ++it) {
-        const bool last_pair = (c_kt + 2 == w.nk);
+        const bool tail_item = TAILABLE && c_n == tail_n;          // (its raw tile is written in the drain: no epilogue set-up)
+        const bool last_pair = (c_kt + 2 == (tail_item ? w.tail_nk : w.nk));
         int kx32 = 32;
         asm volatile("" : "+s"(kx32));
         bool epi_was;
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         PP_RAW_WAIT(false);
         PP_COMPUTE(3, fb1, PP_PIN_A(), false);
         // phase 8: on the last k-tile pair of an output tile, request the operands of the first epilogue quadrant
-        if (last_pair) {
+        if (last_pair && !tail_item) {
             if (GROUPABLE && w.nprob) {
                 work_decode_grouped(w, w_first + c_n * w_stride, et.q, et.m0, et.n0, et.split);
                 et.batch = 0;
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             const bool live = s_live;
             PP_STAGE(1, 1);
             pf_after = live ? 2 : 0;
-            if (last_pair && has_ops) {
+            if (last_pair && has_ops && !tail_item) {
                 // exact count: the 8 younger DMA instructions plus the operand loads just issued are all loads (in order)
                 if (!live) PP_VMCNT(0);
                 else if (npf == 5) PP_VMCNT(13);
@@ -559,13 +572,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             PP_VMCNT(0);                                                                                                \
         }                                                                                                               \
     } while (0)
-    PP_DRAIN_Q(0, 0, 0);
-    PP_DRAIN_PF(0, 1);
-    PP_DRAIN_Q(0, 1, 1);
-    PP_DRAIN_PF(1, 1);
-    PP_DRAIN_Q(1, 1, 3);
-    PP_DRAIN_PF(1, 0);
-    PP_DRAIN_Q(1, 0, 2);
+    if (TAILABLE && tail_n >= 0) {
+        // split-K unit: the raw accumulators as a dense 256 x 256 fp32 tile (rows beyond M / N hold clamped-operand products
+        // the fix-up pass never reads)
+        et.cbase = static_cast<char*>(p.tail_ws) + (size_t)blockIdx.x * (size_t)(PT * PT * 4);
+        et.ldc = PT;
+        epi_quadrant<PP_E_F32, 0, 0, true>(p, w, acc[0], et, pre, el);
+        epi_quadrant<PP_E_F32, 0, 1, true>(p, w, acc[1], et, pre, el);
+        epi_quadrant<PP_E_F32, 1, 1, true>(p, w, acc[3], et, pre, el);
+        epi_quadrant<PP_E_F32, 1, 0, true>(p, w, acc[2], et, pre, el);
+    } else {
+        PP_DRAIN_Q(0, 0, 0);
+        PP_DRAIN_PF(0, 1);
+        PP_DRAIN_Q(0, 1, 1);
+        PP_DRAIN_PF(1, 1);
+        PP_DRAIN_Q(1, 1, 3);
+        PP_DRAIN_PF(1, 0);
+        PP_DRAIN_Q(1, 0, 2);
+    }
     if (tl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store drain
         if (tid == 0) {
@@ -577,6 +601,77 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
             tl[13] = ((long long)xcc << 32) | hw;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second launch of the tail form: out tile = epilogue(sum of the tail_split raw fp32 partials of a left-over tile).  One thread
+// per 16-byte piece of the output (8 columns); the arithmetic after the sum is the one epi_quadrant applies to a whole tile
+// (bf16(alpha * acc + bias) first, then activation / gated residual / activation derivative on that bf16 value).
+// r tiles x 64 Ki elements: a few microseconds, bound by the launch itself.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void pp_tail_fixup_kernel(md_gemm_args p, PPPlan w) {
+    const int t = blockIdx.x >> 5;                                   // left-over tile
+    const int e = (blockIdx.x & 31) * 256 + threadIdx.x;             // 16-byte piece inside the tile: row e / 32, columns 8 (e % 32) ..
+    const int row = e >> 5, c8 = (e & 31) * 8;
+    int m0, n0, batch, split;
+    work_decode(w, w.tail_first + t, m0, n0, batch, split);
+    const int gr = m0 + row, gc = n0 + c8;
+    if (gr >= w.M || gc >= w.N) return;                              // N % 8 == 0: a piece is all inside or all outside
+    const float* src = static_cast<const float*>(p.tail_ws) + ((size_t)t * w.tail_split) * (size_t)(PT * PT) + row * PT + c8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < w.tail_split; ++j) {                         // fixed order: deterministic
+        const float4 a = *reinterpret_cast<const float4*>(src + (size_t)j * (PT * PT));
+        const float4 b = *reinterpret_cast<const float4*>(src + (size_t)j * (PT * PT) + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= p.alpha;
+    if (EPI != PP_E_DACT_GELU && p.bias) {
+        const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)batch * p.sBias + gc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bp[i];
+    }
+    const uint4 T = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+    if (EPI != PP_E_DACT_GELU && p.C2)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (int64_t)batch * p.sC2 + (int64_t)gr * p.ldc2 + gc) = T;
+    uint4 out = T;
+    if constexpr (EPI == PP_E_BF16_GELU) {
+        float y[8];
+        unpack8(T, y);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2 g2 = gelu_erf_2(f32x2{y[i], y[i + 1]});
+            y[i] = g2.x;
+            y[i + 1] = g2.y;
+        }
+        out = make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
+    } else if constexpr (EPI == PP_E_RES) {
+        float y[8], r[8], g[8];
+        unpack8(T, y);
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)gr * p.ldr + gc), r);
+        if (p.gate) {
+            unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.gate) + (int64_t)(gr / p.rows_per_sample) * p.ldg + gc), g);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = 1.f;
+        }
+        out = make_uint4(cvt_pk_bf16(r[0] + g[0] * y[0], r[1] + g[1] * y[1]), cvt_pk_bf16(r[2] + g[2] * y[2], r[3] + g[3] * y[3]),
+                         cvt_pk_bf16(r[4] + g[4] * y[4], r[5] + g[5] * y[5]), cvt_pk_bf16(r[6] + g[6] * y[6], r[7] + g[7] * y[7]));
+    } else if constexpr (EPI == PP_E_DACT_GELU) {
+        float y[8], ax[8];
+        unpack8(T, y);
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.aux) + (int64_t)batch * p.sAux + (int64_t)gr * p.ldaux + gc), ax);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2 d = dgelu_erf_2(f32x2{ax[i], ax[i + 1]});
+            y[i] *= d.x;
+            y[i + 1] *= d.y;
+        }
+        out = make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (int64_t)batch * p.sC + (int64_t)gr * p.ldc + gc) = out;
 }
 
 }  // namespace
@@ -619,13 +714,43 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     return true;
 }
 
+// Whole rounds + split-K tail (md_gemm_args.tail_ws).  total = R * G + r items on G workgroups: without the tail the r left-over
+// tiles cost a whole round (one tile time, ~3 us per pair of k-tiles); with it they cost 1 / s of a round plus the raw-tile
+// write and the fix-up launch (~10 us together).  Taken when that is a gain by the model below (tail_mode 0) or whenever the
+// structure allows it (tail_mode 2): bf16-output epilogue, one operand pair, at least one whole round, r <= G / 2, a split
+// s >= 2 that divides the k-loop into whole iterations (two k-tiles) with r * s <= G, and the workspace holds r * s raw tiles.
+static bool md_gemm_pp_plan_tail(const md_gemm_args* a, int epi, int cus, PPPlan* w) {
+    if (!a->tail_ws || a->tail_mode == 1 || epi == PP_E_F32 || a->A_list || a->problems || a->timeline) return false;
+    const int G = cus & ~7;                      // whole tiles are dealt XCD by XCD: every XCD needs the same number of workgroups
+    if (G < 8 || w->total <= G) return false;
+    const int r = w->total % G;
+    if (r == 0 || r * 2 > G) return false;
+    const int iters = w->nk >> 1;
+    int s = 0;
+    for (int c = iters; c >= 2; --c)
+        if (iters % c == 0 && (int64_t)r * c <= G) { s = c; break; }
+    if (s < 2 || (int64_t)r * s * (PT * PT * 4) > a->tail_ws_bytes) return false;
+    if (a->tail_mode != 2) {
+        const double tile_us = 3.0 * iters;
+        if (tile_us * (1.0 - 1.0 / s) < 14.0) return false;
+    }
+    w->tail_first = w->total - r;
+    w->tail_units = r * s;
+    w->tail_split = s;
+    w->tail_nk = w->nk / s;
+    return true;
+}
+
 int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
     PPPlan w;
     if (!md_gemm_pp_plan(a, &w)) return MD_BAD_ARG;
     const int cus = (a->cu_limit > 0 && a->cu_limit < NUM_CU) ? a->cu_limit : NUM_CU;     // md_gemm_args.cu_limit: CUs left to a collective
-    const unsigned G = (unsigned)(w.total < cus ? w.total : cus);
-    const dim3 grid(G, 1, 1), block(512);
+    unsigned G = (unsigned)(w.total < cus ? w.total : cus);
     const int epi = md_gemm_pp_epi_kind(a);
+    const bool tail = md_gemm_pp_plan_tail(a, epi, cus, &w);
+    if (tail) G = (unsigned)(cus & ~7);
+    if (a->tail_used) *a->tail_used = tail ? w.tail_split : 0;
+    const dim3 grid(G, 1, 1), block(512);
 #define PP_LAUNCH(AK, BK, E) hipLaunchKernelGGL((gemm_bf16_pp_kernel<AK, BK, E>), grid, block, 0, stream, *a, w)
 #ifdef PP_EXPERIMENT_ONE   // compile-time experiments: a single instantiation
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<PP_EXPERIMENT_ONE>), grid, block, 0, stream, *a, w);
@@ -646,5 +771,15 @@ int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
 #endif
 #undef PP_LAUNCH
     MD_LAUNCH_CHECK();
+    if (tail) {
+        const dim3 fgrid((unsigned)(w.tail_units / w.tail_split) * 32u), fblock(256);
+#define PP_FIXUP(E) hipLaunchKernelGGL((pp_tail_fixup_kernel<E>), fgrid, fblock, 0, stream, *a, w)
+        if (epi == PP_E_BF16) PP_FIXUP(PP_E_BF16);
+        else if (epi == PP_E_BF16_GELU) PP_FIXUP(PP_E_BF16_GELU);
+        else if (epi == PP_E_RES) PP_FIXUP(PP_E_RES);
+        else PP_FIXUP(PP_E_DACT_GELU);
+#undef PP_FIXUP
+        MD_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -137,6 +137,10 @@ struct PPPlan {
     int rps_shift;                 // log2(rows_per_sample) when that is a power of two, else -1 (gated residual only)
     int nseg, nk_seg;              // operand lists: segments per item and k-tiles per segment (nseg <= 1: one operand pair per item)
     int nprob;                     // grouped launch: number of problems (0 = the single problem of md_gemm_args)
+    // "whole rounds + split-K tail" (md_gemm_args.tail_ws): items [0, tail_first) are dealt to the workgroups as whole tiles;
+    // item tail_first + u / tail_split is cut along K into tail_split units of tail_nk k-tiles, unit u = workgroup u's LAST
+    // item, written as a raw 256 x 256 fp32 tile to tail_ws + u * 256 KiB (pp_tail_fixup_kernel finishes those tiles).
+    int tail_first, tail_units, tail_split, tail_nk;   // tail_units = 0: no tail
     PPProblem prob[PP_MAX_PROB];
 };
 
@@ -391,6 +395,8 @@ inline bool md_gemm_pp_plan(const md_gemm_args* a, PPPlan* w) {
     w->ksplit = a->ksplit;
     w->lda = (int)a->lda;
     w->ldb = (int)a->ldb;
+    w->tail_first = w->total;
+    w->tail_units = w->tail_split = w->tail_nk = 0;
     w->rps_shift = -1;
     if (a->rows_per_sample > 0 && (a->rows_per_sample & (a->rows_per_sample - 1)) == 0) {
         w->rps_shift = 0;

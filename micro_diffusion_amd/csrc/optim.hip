@@ -161,6 +161,44 @@ extern "C" int md_sumsq_finish(const float* partials, int64_t count, float* out,
     return 0;
 }
 
+// Exact checksum of n 16-bit words (the bf16 shadow weights): out[0] += sum of the words, out[1] += sum of word * odd 32-bit
+// multiplier of its index -- integer sums are exact and order-independent (bit-identical on identical data whatever the
+// schedule), one flipped bf16 ulp, a sign flip or two swapped elements all change them.  n % 8 == 0, out zeroed by the caller.
+__global__ __launch_bounds__(256) void checksum_u16_kernel(const uint4* x, int64_t n8, unsigned long long* out) {
+    unsigned long long s0 = 0, s1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = x[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long lo = w[e] & 0xffffu, hi = w[e] >> 16;
+            const unsigned long long i0 = (unsigned long long)i * 8 + 2 * e, i1 = i0 + 1;
+            s0 += lo + hi;
+            s1 += lo * (((i0 * 0x9E3779B97F4A7C15ull) >> 32) | 1ull) + hi * (((i1 * 0x9E3779B97F4A7C15ull) >> 32) | 1ull);
+        }
+    }
+    // wave-level integer reduction, then one atomic pair per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, s0);
+        atomicAdd(out + 1, s1);
+    }
+}
+
+extern "C" int md_checksum_u16(const void* x, int64_t n, uint64_t* out2, hipStream_t st) {
+    if (!x || !out2 || n <= 0 || n % 8 || ((uintptr_t)x & 15)) return MD_BAD_ARG;
+    int64_t grid = (n / 8 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(checksum_u16_kernel, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const uint4*>(x), n / 8,
+                       reinterpret_cast<unsigned long long*>(out2));
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int md_adamw_step(const md_adamw_args* a, hipStream_t st) {
     if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0 || a->n % 4) return MD_BAD_ARG;
     if (a->ema_mode < 0 || a->ema_mode > 2 || (a->ema_mode && !a->ema)) return MD_BAD_ARG;

@@ -227,11 +227,14 @@ class DiT(nn.Module):
         detected through the parameters' autograd version counters, which every in-place update bumps."""
         f = self._flat
         ver = self._param_version()
-        if ver != self._shadow_version and getattr(self, "shadow_is_authoritative", False):
+        if (force or ver != self._shadow_version) and getattr(self, "shadow_is_authoritative", False):
+            # (`force` too: callers that write the flat master buffer directly -- EMA swap, sync_replicas -- do not bump the
+            # Parameters' version counters, and a forced cast from stale masters is the same corruption: ADVICE r4)
             # sharded optimiser: this rank's fp32 masters of the OTHER ranks' chunks are stale and the bf16 shadow (all-gathered)
             # is the only complete copy of the weights -- re-deriving it from the masters would silently corrupt them
-            raise RuntimeError("a parameter was modified in place while the sharded optimiser holds stale fp32 masters of foreign "
-                               "chunks: call Trainer.consolidate() first (it all-gathers masters and moments)")
+            raise RuntimeError("the bf16 shadow would be re-derived from the fp32 masters while the sharded optimiser holds stale "
+                               "masters of foreign chunks (a parameter was modified in place, or swap_ema / sync_replicas ran): call "
+                               "Trainer.consolidate() first (it all-gathers masters and moments)")
         if force or ver != self._shadow_version:
             hip.check(hip.lib().md_cast_f32_bf16(f["p"].data_ptr(), f["s"].data_ptr(), f["total"], None,
                                                  torch.cuda.current_stream().cuda_stream), "md_cast_f32_bf16")

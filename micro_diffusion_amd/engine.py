@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from ctypes import byref
 from typing import Dict, List, Optional
 
@@ -29,6 +30,7 @@ from . import hip
 from .arch import BlockPlan, DiTConfig, caption_ffn_hidden, plan_blocks
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+TAIL_WS_BYTES = 256 * 256 * 256 * 4     # md_gemm_args.tail_ws: one raw 256 x 256 fp32 tile per workgroup (64 MiB of the split-K workspace)
 
 
 class Tape:
@@ -132,6 +134,7 @@ class DiTEngine:
         self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
+        self.gemm_tail_mode = int(os.environ.get("MD_GEMM_TAIL", "0"))   # md_gemm_args.tail_mode: 0 = the library decides, 1 = never, 2 = always (A/B)
         self.cu_limit_fn = None     # data parallelism: callable() -> CUs the persistent GEMM may occupy right now (0 = all): the
         #                             Trainer leaves the CUs of RCCL's channels free while a collective is in flight
 
@@ -186,6 +189,10 @@ class DiTEngine:
         a.chosen_variant = ctypes.addressof(chosen)
         if self.cu_limit_fn is not None:
             a.cu_limit = self.cu_limit_fn()
+        if self.gemm_tail_mode != 1 and a.mode in (hip.EPI_STORE_BF16, hip.EPI_RESIDUAL, hip.EPI_DACT):
+            # whole rounds + split-K tail (md_gemm_args.tail_ws): bf16-output launches never use the split-K workspace themselves,
+            # and everything that does is ordered behind them on this stream
+            a.tail_ws, a.tail_ws_bytes, a.tail_mode = self.ws.data_ptr(), TAIL_WS_BYTES, self.gemm_tail_mode
         rc = hip.NOT_ELIGIBLE
         want = self.gemm_prefer if self.gemm_prefer != hip.GEMM_AUTO else a.variant
         if want != hip.GEMM_AUTO:

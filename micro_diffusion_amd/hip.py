@@ -116,11 +116,12 @@ class GemmArgs(Structure):
         ("mode", c_int32), ("act", c_int32), ("alpha", c_float), ("variant", c_int32), ("raster_group_n", c_int32),
         ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p), ("list_segments", c_int32),
         ("problems", c_void_p), ("n_problems", c_int32), ("cu_limit", c_int32),
+        ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64), ("tail_mode", c_int32), ("tail_used", c_void_p),
     ]
 
 
 _lib = None
-ABI_VERSION = 4        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
+ABI_VERSION = 5        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
 
 
 def lib() -> ctypes.CDLL:
@@ -244,6 +245,7 @@ _sig("md_edm_sampler_input", P, P, I64, F32, F32, I32, P)
 _sig("md_edm_heun_update", P, P, P, P, P, I64, F32, I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, F32, I32, P)
 _sig("md_sumsq", P, I32, I64, P, P)
 _sig("md_sumsq_finish", P, I64, P, P)
+_sig("md_checksum_u16", P, I64, P, P)
 _sig("md_adamw_step", POINTER(AdamWArgs), P)
 _sig("md_adamw_step_ranges", POINTER(AdamWArgs), P, P, I32, P)
 
@@ -270,8 +272,10 @@ def stream_ptr():
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mode=EPI_STORE_BF16,
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
-         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None, cu_limit=0):
-    """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors."""
+         variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None, cu_limit=0,
+         tail_ws=None, tail_mode=0, tail_used=None):
+    """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors.  tail_ws: a torch tensor used as the
+    workspace of the whole-rounds + split-K-tail form (md_gemm_args.tail_ws); tail_used: list that receives the split it ran with (0 = not used)."""
     def ptr(x):
         if x is None:
             return None
@@ -279,12 +283,16 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
     a = GemmArgs(ptr(A), ptr(B), ptr(C), ptr(C2), ptr(bias), ptr(res), ptr(gate), ptr(aux),
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
-                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0, cu_limit)
-    ch = ctypes.c_int32(-1)
+                 ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0, cu_limit,
+                 ptr(tail_ws), (tail_ws.numel() * tail_ws.element_size()) if tail_ws is not None else 0, tail_mode, None)
+    ch, tu = ctypes.c_int32(-1), ctypes.c_int32(-1)
     a.chosen_variant = ctypes.addressof(ch)
+    a.tail_used = ctypes.addressof(tu)
     rc = lib().md_gemm_bf16(byref(a), stream if stream is not None else stream_ptr())
     if chosen is not None:
         chosen.append(ch.value)
+    if tail_used is not None:
+        tail_used.append(tu.value)
     if expect is None:
         return rc
     check(rc, "md_gemm_bf16")

@@ -221,6 +221,67 @@ def gen_curve_hot(steps=1000):
     print("tiny_curve_hot.npz")
 
 
+XL2_CURVE_TENSORS = ("final_layer.linear.weight", "patch_mixer.1.mlp.gate.weight", "blocks.0.attn.qkv.weight", "blocks.13.mlp.w1",
+                     "blocks.27.adaLN_modulation.1.weight", "x_embedder.proj.weight")
+
+
+def _xl2_curve_slice(name, t):
+    """The part of a tensor the fixture keeps (whole small tensors, a 64 x 64 corner of the large ones)."""
+    t = t.detach()
+    if t.dim() == 4:                      # conv weight [D, C, p, p]
+        return t.flatten(1)[:64].clone()
+    if t.dim() == 3:                      # expert weights [E, in, out]: expert 0
+        return t[0, :64, :64].clone()
+    return t[:64, :64].clone()
+
+
+XL2_CURVE_FIRST_BATCH = 100     # the 8 steps are batches 100 .. 107 of the YAML's schedule (lr 9.6e-6 .. 1.03e-5)
+
+
+def gen_curve_xl2(steps=8, B=4):
+    """`steps` optimiser steps of the UNMODIFIED reference at MicroDiT_XL_2 widths (dit.py:671-709; model.py:181-210
+    produces the loss series) -- torch AdamW (lr 2.4e-4, wd 0.1), clip_grad_norm_(0.25), the YAML's cosine schedule with its
+    2500-batch linear warm-up (configs/res_256_pretrain.yaml:52-61) entered at batch 100 (a non-zero learning rate; ramping to
+    the full 2.4e-4 within 8 steps instead makes the de-zeroed network diverge -- loss 1.3 -> 4.6 -- in the reference itself),
+    seed-18 initialisation with the all-zero tensors de-zeroed (the network matters from step 0), batch 4, recorded noise
+    (oracle.curve_inputs).  Records per-step loss, pre-clip gradient norm and initial / final values of slices of six named
+    tensors."""
+    cfg = orc.xl2_config()
+    torch.manual_seed(18)
+    dit = ref_dit_from_cfg(cfg)
+    dit.load_state_dict(orc.dezero_state_dict({k: v.detach().clone() for k, v in dit.state_dict().items()}))
+    model = ref_latent_diffusion(dit, -0.6, 1.2, 0.75)
+    model.train()
+    opt = torch.optim.AdamW(dit.parameters(), lr=2.4e-4, weight_decay=0.1, eps=1e-8, betas=(0.9, 0.999))
+    named = dict(dit.named_parameters())
+    out = {}
+    for k in XL2_CURVE_TENSORS:
+        out["init/" + k] = _xl2_curve_slice(k, named[k]).numpy()
+    losses, gnorms = [], []
+    import time
+    for step in range(steps):
+        t0 = time.time()
+        batch, rnd, epsn, mnoise = orc.curve_inputs(cfg, step, batch=B, pool=4 * B, pool_seed=78)
+        rec = Recorded([rnd, epsn], [mnoise])
+        model.randn_like = lambda x: rec.randn()
+        for gr in opt.param_groups:
+            gr["lr"] = 2.4e-4 * orc.lr_factor("cosine_with_warmup", XL2_CURVE_FIRST_BATCH + step, 2500, 250000, 0.33)
+        with mock.patch.object(torch, "randn", rec.randn), mock.patch.object(torch, "rand", rec.rand):
+            loss, _, _ = model(batch)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(dit.parameters(), 0.25)
+        opt.step()
+        losses.append(loss.item())
+        gnorms.append(gn.item())
+        print(step, loss.item(), gn.item(), f"{time.time() - t0:.1f}s", flush=True)
+    for k in XL2_CURVE_TENSORS:
+        out["final/" + k] = _xl2_curve_slice(k, named[k]).numpy()
+    np.savez_compressed(os.path.join(OUT, "xl2_curve.npz"), loss=np.array(losses), gnorm=np.array(gnorms), steps=np.int64(steps),
+                        batch=np.int64(B), first_batch=np.int64(XL2_CURVE_FIRST_BATCH), **out)
+    print("xl2_curve.npz")
+
+
 def gen_sampler():
     """The reference's Heun sampler (model.py:231-297) with and without classifier-free guidance (dit.py:521-550) on the
     tiny config: pins oracle.edm_sampler."""
@@ -298,6 +359,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "curve":
         gen_curve()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2_curve":
+        gen_curve_xl2()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "curve_hot":
         gen_curve_hot()

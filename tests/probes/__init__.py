@@ -15,6 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 def build(force: bool = False) -> str:
     import fcntl
+    h0 = hashlib.sha256(open(_SRC, "rb").read() + " ".join(FLAGS).encode()).hexdigest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(_HASH_PATH) and open(_HASH_PATH).read().strip() == h0:
+        return LIB_PATH                          # up to date: no lock file is touched
     with open(os.path.join(_HERE, ".libmd_probes.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:

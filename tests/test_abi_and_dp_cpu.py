@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.md_abi_version() == 4 == hip.ABI_VERSION
-    assert re.search(r"#define MD_ABI_VERSION 4\b", header)
+    assert lib.md_abi_version() == 5 == hip.ABI_VERSION
+    assert re.search(r"#define MD_ABI_VERSION 5\b", header)
 
 
 def test_product_never_imports_oracle():
@@ -292,12 +292,12 @@ def test_comm_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     header = open(os.path.join(ROOT, "include", "microdit_comm.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(md_comm_\w+)\s*\(", header, flags=re.M))
-    assert len(declared) == 12, declared
+    assert len(declared) == 13, declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(comm.exported_symbols()), declared ^ set(comm.exported_symbols())
     L = comm.lib()
-    assert L.md_comm_abi_version() == 1 == comm.ABI_VERSION
+    assert L.md_comm_abi_version() == 2 == comm.ABI_VERSION
     assert L.md_comm_unique_id(None) == -1
     h = ctypes.c_void_p()
     uid = ctypes.create_string_buffer(128)
@@ -383,13 +383,28 @@ def test_rccl_channel_cap_and_in_flight_host_logic(monkeypatch):
     assert tr.cap_rccl_channels(16) == 4 and os.environ["NCCL_MIN_NCHANNELS"] == "4"     # the user's cap wins, MIN never exceeds it
     monkeypatch.setenv("NCCL_MAX_NCHANNELS", "not-a-number")
     assert tr.rccl_channel_cap() == 0
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "not-a-number")
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS", raising=False)
+    assert tr.cap_rccl_channels() == 0 and "NCCL_MIN_NCHANNELS" not in os.environ      # no ValueError on a non-numeric export
     sync = tr.GradSync(_FakeDiT(0))                          # no process group: a single rank, nothing in flight
     assert not sync.enabled and not sync.in_flight()
-    sync.pending.append(object())
+
+    class Work:                                              # torch.distributed's Work / comm.Ticket as far as in_flight() cares
+        def __init__(self):
+            self.done = False
+
+        def is_completed(self):
+            return self.done
+
+    a, b, c = Work(), Work(), Work()
+    sync.pending.append(sync._track(a))
+    sync.pending.append(sync._track(b))
+    sync.gather_work["blocks.0"] = [sync._track(c)]
     assert sync.in_flight()
-    sync.pending.clear()
-    sync.gather_work["blocks.0"] = [object()]
+    a.done = True
+    assert sync.in_flight() and len(sync._wire) == 2          # the finished handle was dropped from the front, b still on the wire
+    b.done = c.done = True
+    assert not sync.in_flight()                               # the wire is idle: the GEMM grids get their CUs back although finish() /
+    assert sync.pending and sync.gather_work                  # wait_gather() have not consumed the handles yet
+    sync._track(object())                                     # a handle that cannot be queried counts as busy
     assert sync.in_flight()
-    sync.wait_gather = lambda key=None: sync.gather_work.clear()
-    sync.wait_gather()
-    assert not sync.in_flight()

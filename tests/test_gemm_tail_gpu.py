@@ -1,0 +1,204 @@
+"""The "whole rounds + split-K tail" form of the persistent GEMM (md_gemm_args.tail_ws, gemm_pp.hip): when the output tiles of a
+launch do not make whole rounds of its workgroups -- the north_star's own per-rank shape: 16,384 x 1024 = 256 tiles on the 248
+CUs an 8-channel RCCL kernel leaves (/root/reference/configs/res_256_pretrain.yaml:111 with train.py:50) -- the left-over tiles
+are cut along K, every workgroup runs one unit after its whole tiles in the same k-tile stream, and a fix-up launch sums the raw
+fp32 partials and applies the epilogue.  Every epilogue kind, against torch fp32 of the same bf16 operands AND against the same
+launch without the tail (the two may differ by bf16 roundings of a different fp32 summation order, nothing else).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+TAIL_OFF, TAIL_FORCE = 1, 2
+
+
+@pytest.fixture(scope="module")
+def tws():
+    return torch.empty(256 * 256 * 256, device=dev, dtype=torch.float32)      # 64 MiB: one raw tile per workgroup
+
+
+def _operand(rows, k, kcontig, scale=1.0):
+    t = (torch.randn(rows, k, device=dev) * scale).to(torch.bfloat16)
+    return (t, t, k) if kcontig else (t, t.t().contiguous(), rows)
+
+
+def _close(out, ref, rel=2e-2, what=""):
+    err = (out.float() - ref).abs().max().item()
+    lim = rel * ref.abs().max().item() + 1e-3
+    assert err <= lim, f"{what}: max err {err} > {lim}"
+
+
+def _same_but_roundings(a, b, what, frac=0.05, ulps=2):
+    """Two bf16 results of the same contraction summed in a different fp32 order: a few elements may round the other way."""
+    d = (a.float() - b.float()).abs()
+    tol = ulps * 2.0 ** -8 * torch.maximum(a.float().abs(), b.float().abs()) + 1e-6
+    assert bool((d <= tol).all()), f"{what}: tail and whole-tile results differ by more than {ulps} bf16 ulps (max {d.max().item()})"
+    assert (d > 0).float().mean().item() <= frac, f"{what}: {(d > 0).float().mean().item():.3f} of the elements differ"
+
+
+def _pair(hip, tws, expect_split, **kw):
+    """Run once without and once with the tail; returns (whole-tile result holders filled, split used)."""
+    used = []
+    hip.gemm(variant=hip.GEMM_PP256, tail_ws=tws, tail_mode=TAIL_FORCE, tail_used=used, **kw)
+    torch.cuda.synchronize()
+    assert used[0] >= 2, f"the tail form was not launched (split {used[0]})"
+    if expect_split:
+        assert used[0] == expect_split, used
+    return used[0]
+
+
+# (M, N, K, akc, bkc, cu_limit, split): the per-rank shapes of an 8-GPU run under RCCL's CU hold, shapes with a ragged last round
+# on the free chip, ragged M / N (tail tiles with clamped rows and columns)
+TAIL_SHAPES = [
+    (16384, 1024, 1024, 1, 1, 248, 8), (16384, 1024, 1024, 1, 0, 248, 8), (16384, 1024, 768, 1, 1, 248, 6),
+    (65536, 768, 768, 1, 1, 248, 6), (16384, 2304, 1024, 1, 1, 0, 4), (16384 + 72, 1024 + 40, 1152, 1, 1, 0, 3),
+    (16384 + 72, 1024 + 40, 1152, 1, 0, 0, 3),
+]
+
+
+@pytest.mark.parametrize("M,N,K,akc,bkc,cu,split", TAIL_SHAPES)
+def test_tail_plain_store(hip, tws, M, N, K, akc, bkc, cu, split):
+    torch.manual_seed(M + N + K + akc + 2 * bkc)
+    A, As, lda = _operand(M, K, akc)
+    B, Bs, ldb = _operand(N, K, bkc, 0.05)
+    kw = dict(A=As, B=Bs, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kcontig=akc, b_kcontig=bkc, cu_limit=cu)
+    C0 = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    C1 = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    off = []
+    hip.gemm(C=C0, variant=hip.GEMM_PP256, tail_ws=tws, tail_mode=TAIL_OFF, tail_used=off, **kw)
+    assert off == [0]
+    _pair(hip, tws, split, C=C1, **kw)
+    ref = A.float() @ B.float().t()
+    _close(C0, ref, what="whole tiles")
+    _close(C1, ref, what="tail form")
+    _same_but_roundings(C0, C1, f"{M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,bkc,rps,cu", [(16384, 1024, 2816, 1, 64, 248), (16384, 1024, 1024, 1, 256, 248), (16384, 2304, 1024, 0, 0, 0)])
+def test_tail_gated_residual(hip, tws, M, N, K, bkc, rps, cu):
+    """proj / w3 epilogue (dit.py:236,238) and the plain residual accumulate of a dgrad on left-over tiles."""
+    torch.manual_seed(7 + M + K)
+    A, As, lda = _operand(M, K, 1)
+    B, Bs, ldb = _operand(N, K, bkc, 0.05)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    raw = A.float() @ B.float().t()
+    if rps:
+        gate = torch.randn((M + rps - 1) // rps, N, device=dev).to(torch.bfloat16)
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        C2 = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _pair(hip, tws, 0, A=As, B=Bs, C=out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kcontig=1, b_kcontig=bkc, mode=hip.EPI_RESIDUAL,
+              res=res, ldr=N, gate=gate, ldg=N, rows_per_sample=rps, C2=C2, ldc2=N, cu_limit=cu)
+        ref = res.float() + gate.float().repeat_interleave(rps, 0)[:M] * raw.to(torch.bfloat16).float()
+        _close(C2, raw, what="raw copy")
+    else:
+        out = res.clone()
+        _pair(hip, tws, 0, A=As, B=Bs, C=out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kcontig=1, b_kcontig=bkc, mode=hip.EPI_RESIDUAL,
+              res=out, ldr=N, cu_limit=cu)
+        ref = res.float() + raw.to(torch.bfloat16).float()
+    _close(out, ref, what="tail residual")
+
+
+def test_tail_moe_grouped(hip, tws):
+    """The batched (8-expert) launches with their strides: fc1 with GELU-erf + raw copy, fc2 dgrad through GELU' (aux operand)."""
+    torch.manual_seed(11)
+    E, Bk, d, f = 8, 4096, 1024, 3840                      # 16 x 15 x 8 = 1920 tiles = 7 rounds of 256 + 128: split 2
+    X = torch.randn(E, Bk, d, device=dev).to(torch.bfloat16)
+    W1 = (torch.randn(E, d, f, device=dev) * 0.03).to(torch.bfloat16)
+    W2 = (torch.randn(E, f, d, device=dev) * 0.03).to(torch.bfloat16)
+    H = torch.full((E, Bk, f), float("nan"), device=dev, dtype=torch.bfloat16)
+    Hp = torch.full((E, Bk, f), float("nan"), device=dev, dtype=torch.bfloat16)
+    _pair(hip, tws, 2, A=X, B=W1, C=H, C2=Hp, M=Bk, N=f, K=d, lda=d, ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f, sC2=Bk * f,
+          batch=E, a_kcontig=1, b_kcontig=0, act=hip.ACT_GELU_ERF)
+    raw = torch.einsum("erd,edf->erf", X.float(), W1.float())
+    _close(Hp, raw, what="fc1 raw")
+    _close(H, torch.nn.functional.gelu(raw), what="fc1 gelu")
+    dO = torch.randn(E, Bk, d, device=dev).to(torch.bfloat16)
+    dHp = torch.full((E, Bk, f), float("nan"), device=dev, dtype=torch.bfloat16)
+    _pair(hip, tws, 2, A=dO, B=W2, C=dHp, aux=Hp, M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d, sC=Bk * f, sAux=Bk * f,
+          batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF)
+    xp = Hp.float().requires_grad_(True)
+    torch.nn.functional.gelu(xp).sum().backward()
+    _close(dHp, torch.einsum("erd,efd->erf", dO.float(), W2.float()) * xp.grad, what="dact")
+
+
+def test_tail_refused_where_it_does_not_apply(hip, tws):
+    """Whole rounds (nothing left over), a left-over larger than half a round, fp32 slices: the plain form runs, tail_used = 0."""
+    A = torch.randn(65536, 256, device=dev).to(torch.bfloat16)
+    B = torch.randn(1024, 256, device=dev).to(torch.bfloat16)
+    C = torch.empty(65536, 1024, device=dev, dtype=torch.bfloat16)
+    for M, cu in ((65536, 0), (256 * 50, 0)):      # 1024 tiles = 4 whole rounds; 200 tiles < one round
+        used = []
+        hip.gemm(A, B, C, M, 1024, 256, lda=256, ldb=256, ldc=1024, variant=hip.GEMM_PP256, tail_ws=tws, tail_mode=TAIL_FORCE, tail_used=used, cu_limit=cu)
+        assert used == [0], (M, used)
+    used = []
+    hip.gemm(A, B, C, 256 * 100, 1024, 256, lda=256, ldb=256, ldc=1024, variant=hip.GEMM_PP256, tail_ws=tws, tail_mode=TAIL_FORCE, tail_used=used)
+    assert used == [0], used                         # 400 tiles: 144 left over > 128
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0)])
+def test_tail_race_screen(hip, tws, akc, bkc):
+    """Bit-identical results over repeated launches (the tail unit shares the LDS ring and the epilogue hand-over with the whole
+    tiles before it; the fix-up sums in a fixed order), idle and with another stream streaming through HBM."""
+    torch.manual_seed(19)
+    M, N, K = 256 * 70 + 40, 1024 + 8, 512              # 71 x 5 = 355 tiles = 1 round + 99: split 2, ragged edge tiles in the tail
+    A, As, lda = _operand(M, K, akc)
+    B, Bs, ldb = _operand(N, K, bkc, 0.1)
+    outs = []
+    noise_stream = torch.cuda.Stream()
+    big = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
+    for rep in range(6):
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        if rep >= 3:
+            with torch.cuda.stream(noise_stream):
+                for _ in range(4):
+                    big.add_(1)
+        _pair(hip, tws, 2, A=As, B=Bs, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, a_kcontig=akc, b_kcontig=bkc)
+        outs.append(C)
+    _close(outs[0], A.float() @ B.float().t(), what="tail")
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "tail form: result differs between identical launches"
+
+
+def _time_us(fn, reps=8):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e30
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def test_cu_limit_on_the_rank_of_8_shape(hip, tws):
+    """16,384 x 1024 x 1024 (one tile per CU on the free chip) under cu_limit 248.  Whole tiles only: two rounds
+    (~2x).  With the tail: one round + 1/8 of a round + the fix-up launch.  Reported in gpurun_out/, asserted <= 1.35x."""
+    M, N, K = 16384, 1024, 1024
+    torch.manual_seed(5)
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kw = dict(A=A, B=B, C=C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, variant=hip.GEMM_PP256, tail_ws=tws)
+    t_free = _time_us(lambda: hip.gemm(tail_mode=TAIL_OFF, **kw), reps=16)
+    t_lim = _time_us(lambda: hip.gemm(tail_mode=TAIL_OFF, cu_limit=248, **kw), reps=16)
+    t_tail = _time_us(lambda: hip.gemm(tail_mode=0, cu_limit=248, **kw), reps=16)
+    used = []
+    hip.gemm(tail_mode=0, cu_limit=248, tail_used=used, **kw)
+    torch.cuda.synchronize()
+    out = {"shape": [M, N, K], "free_chip_us": t_free, "cu248_whole_tiles_us": t_lim, "cu248_tail_us": t_tail, "split": used[0],
+           "ratio_whole_tiles": t_lim / t_free, "ratio_tail": t_tail / t_free}
+    print(json.dumps(out))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gemm_tail_rank_of_8.json", "w") as fh:
+        json.dump(out, fh, indent=1)
+    assert used[0] == 8, "the library's own rule must take the tail on this shape"
+    assert t_tail <= 1.35 * t_free, out
