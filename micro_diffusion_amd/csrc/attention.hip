@@ -146,6 +146,23 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
         }
 }
 
+// The same with the bf16 value already at the destination added in (block rounds of the long-sequence backward).
+template <int HD>
+__device__ __forceinline__ void store_rows_acc(bf16* dst_row, const f32x16 (&acc)[HD / 32], float mul, int lane) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16* d = dst_row + di * 32 + 8 * g + 4 * hh;
+            const bf16x4 old = ld_bf16x4(d);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[di][4 * g + e] * mul + bf2f(old[e]));
+            st_bf16x4(d, o);
+        }
+}
+
 // (Measured and dropped: capping this kernel at 128 VGPRs -- 117 without a spill at head_dim 64, 4 waves / SIMD instead of 3 --
 // made the 2-wave instantiation 15 % SLOWER in the step, 142.7 -> 164.9 us; the allocation the compiler picks on its own keeps
 // more of a phase's loads in flight.  profiles/r2_attention_two_phase_bwd.txt.)
@@ -622,9 +639,22 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
 // hold two of those workgroups (75.8 KiB of LDS each), where the single-phase kernel (190 VGPRs, 149.5 KiB) holds one and has
 // nothing to overlap its load and store phases with.  Price: S = Q K^T and the exponentials of role 2 are formed twice
 // (20 instead of 16 MFMAs per tile pair).
+// ---------------------------------------------------------------------------------------------------------------------
+// Sequences longer than one image of this kernel (Sq or Skv > 256: the res-512 patch mixer, 1024 tokens, and its cross-attention,
+// 1024 x 77 -- /root/reference/configs/res_512_pretrain.yaml:24, utils.py:188-193): the problem is cut into nqb x nkb blocks of at most
+// 256 x 256.  Given the forward's log-sum-exp (and delta = rowsum(dO * O), a per-row quantity the kernel forms itself) the
+// contributions of the block pairs to dQ / dK / dV are INDEPENDENT sums, so one block pair is exactly this kernel's problem: the
+// host (launch_bwd_fused) launches it once per block pair with the pointers moved to the pair's rows, the pairs ordered so that
+// every output block has ONE writer at a time (stream order), and pairs after an output block's first add into it
+// (store_rows_acc; no atomics, deterministic).  lse_stride = rows per (batch, head) of the log-sum-exp array (the WHOLE Sq);
+// acc_flags bit 0: dQ of this launch accumulates, bit 1: dK / dV do.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ATTN_BLK = 256;
+
 template <int HD, int SQP, int SKP, bool SPLIT2>
 __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) __attribute__((amdgpu_waves_per_eu(SPLIT2 ? 4 : 3)))
-void attn_bwd_fused2_kernel(md_attn_args p) {
+void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
+    const bool acc_q = acc_flags & 1, acc_kv = acc_flags & 2;
     constexpr int PK = (HD + 8) * 2;
     constexpr int RMAX = SQP > SKP ? SQP : SKP;
     constexpr int NT = RMAX * 2;                                       // = blockDim.x: one wave per 32 rows of the taller side
@@ -649,7 +679,7 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
     u32x4 rk[ITK], rv[ITK];
     {
         // every global load of the workgroup in flight before the first LDS write (as in the single-phase kernel)
-        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
+        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * lse_stride;
         u32x4 rq[ITQ], rdo[ITQ], ro[ITQ];
         float rl[ITQ];
         const u32x4 z4 = {0u, 0u, 0u, 0u};
@@ -748,7 +778,8 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
         }
         if (q < p.Sq) {
             bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-            store_rows<HD>(dQ, dqacc, p.scale, lane);
+            if (acc_q) store_rows_acc<HD>(dQ, dqacc, p.scale, lane);
+            else store_rows<HD>(dQ, dqacc, p.scale, lane);
         }
     }
     // this wave's 32 key rows, while K and V are still in LDS
@@ -802,7 +833,10 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                             tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, acc[di], 0, 0, 0);
                 }
             }
-            if (key < p.Skv) store_rows<HD>(dV, acc, 1.f, lane);
+            if (key < p.Skv) {
+                if (acc_kv) store_rows_acc<HD>(dV, acc, 1.f, lane);
+                else store_rows<HD>(dV, acc, 1.f, lane);
+            }
             // pass 2: dK = dS^T Q
 #pragma unroll
             for (int di = 0; di < HD / 32; ++di)
@@ -834,7 +868,10 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                             tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, acc[di], 0, 0, 0);
                 }
             }
-            if (key < p.Skv) store_rows<HD>(dK, acc, p.scale, lane);
+            if (key < p.Skv) {
+                if (acc_kv) store_rows_acc<HD>(dK, acc, p.scale, lane);
+                else store_rows<HD>(dK, acc, p.scale, lane);
+            }
         } else {
             f32x16 dkacc[HD / 32], dvacc[HD / 32];
 #pragma unroll
@@ -875,8 +912,13 @@ void attn_bwd_fused2_kernel(md_attn_args p) {
                 }
             }
             if (key < p.Skv) {
-                store_rows<HD>(dK, dkacc, p.scale, lane);
-                store_rows<HD>(dV, dvacc, 1.f, lane);
+                if (acc_kv) {
+                    store_rows_acc<HD>(dK, dkacc, p.scale, lane);
+                    store_rows_acc<HD>(dV, dvacc, 1.f, lane);
+                } else {
+                    store_rows<HD>(dK, dkacc, p.scale, lane);
+                    store_rows<HD>(dV, dvacc, 1.f, lane);
+                }
             }
         }
     }
@@ -891,12 +933,11 @@ inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 2
 // the 64 x 64 bucket pair, where the single-phase kernel is 10 % ahead (two-wave workgroups: the five extra barriers cost more
 // than 6 instead of 4 resident workgroups return).
 template <int HD>
-bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
-    const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
-    if (!bq || !bk) return false;
+void launch_bwd_fused_one(const md_attn_args* a, int variant, int bq, int bk, int64_t lse_stride, int acc_flags, hipStream_t stream) {
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
-#define FUSED2(SQP, SKP, SPL) hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
+#define FUSED2(SQP, SKP, SPL) \
+    hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a, lse_stride, acc_flags)
 #define SMALL(SQP, SKP)                          \
     do {                                         \
         if (variant == 2 || (variant == 0 && SQP == 64 && SKP == 64)) FUSED(SQP, SKP); \
@@ -921,6 +962,46 @@ bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
 #undef BIG
 #undef FUSED
 #undef FUSED2
+}
+
+template <int HD>
+bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
+    const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
+    if (bq && bk) {
+        launch_bwd_fused_one<HD>(a, variant, bq, bk, a->Sq, 0, stream);
+        return true;
+    }
+    // Longer than one image: one launch per <= 256 x 256 block pair on the two-phase kernel (comment above attn_bwd_fused2_kernel).
+    // Order: rounds r = 0 .. n - 1 of the pairs (qb, (qb + r) mod n), n = max(nqb, nkb) -- within a round no two pairs share an
+    // output block, so a later "launch them side by side" form stays possible; the stream order alone already gives every
+    // output block one writer at a time.
+    if (variant == 2) return false;                               // the single-phase kernel has no block form
+    const int nqb = (int)((a->Sq + ATTN_BLK - 1) / ATTN_BLK), nkb = (int)((a->Skv + ATTN_BLK - 1) / ATTN_BLK);
+    const int n = nqb > nkb ? nqb : nkb;
+    if (n > 16) return false;                                     // > 4096 tokens: the kernel pair
+    unsigned q_written = 0, k_written = 0;                        // bit per block: an earlier pair already stored this output block
+    for (int r = 0; r < n; ++r)
+        for (int qb = 0; qb < nqb; ++qb) {
+            const int kb = (qb + r) % n;
+            if (kb >= nkb) continue;
+            const int64_t q0 = (int64_t)qb * ATTN_BLK, k0 = (int64_t)kb * ATTN_BLK;
+            md_attn_args c = *a;
+            c.q = static_cast<const bf16*>(a->q) + q0 * a->ldq;
+            c.d_o = static_cast<const bf16*>(a->d_o) + q0 * a->lddo;
+            c.o = static_cast<bf16*>(a->o) + q0 * a->ldo;
+            c.dq = static_cast<bf16*>(a->dq) + q0 * a->lddq;
+            c.lse = static_cast<float*>(a->lse) + q0;
+            c.k = static_cast<const bf16*>(a->k) + k0 * a->ldk;
+            c.v = static_cast<const bf16*>(a->v) + k0 * a->ldv;
+            c.dk = static_cast<bf16*>(a->dk) + k0 * a->lddk;
+            c.dv = static_cast<bf16*>(a->dv) + k0 * a->lddv;
+            c.Sq = a->Sq - q0 < ATTN_BLK ? a->Sq - q0 : ATTN_BLK;
+            c.Skv = a->Skv - k0 < ATTN_BLK ? a->Skv - k0 : ATTN_BLK;
+            const int flags = ((q_written >> qb) & 1) | (((k_written >> kb) & 1) << 1);
+            q_written |= 1u << qb;
+            k_written |= 1u << kb;
+            launch_bwd_fused_one<HD>(&c, variant ? variant : 3, fused_bucket(c.Sq), fused_bucket(c.Skv), a->Sq, flags, stream);   // (0 could pick the single-phase kernel, which cannot accumulate)
+        }
     return true;
 }
 

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
         sB += b_kstep;
         if (++s_kt == ((TAILABLE && s_n == tail_n) ? w.tail_nk : w.nk)) {
             s_kt = 0;
-            if (++s_n < w_count) stager_open(s_n);
+            if (++s_n < w_count + (tail_n >= 0 ? 1 : 0)) stager_open(s_n);   // (the tail unit is one more item)
             else s_live = false;
         } else if (EPI == PP_E_F32 && p.A_list && --s_seg_kt == 0) {
             stager_segment(++s_li);                // the item goes on with the next operand pair of its list (same accumulators)
@@ -620,11 +620,20 @@ __global__ __launch_bounds__(256) void pp_tail_fixup_kernel(md_gemm_args p, PPPl
     if (gr >= w.M || gc >= w.N) return;                              // N % 8 == 0: a piece is all inside or all outside
     const float* src = static_cast<const float*>(p.tail_ws) + ((size_t)t * w.tail_split) * (size_t)(PT * PT) + row * PT + c8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < w.tail_split; ++j) {                         // fixed order: deterministic
-        const float4 a = *reinterpret_cast<const float4*>(src + (size_t)j * (PT * PT));
-        const float4 b = *reinterpret_cast<const float4*>(src + (size_t)j * (PT * PT) + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    for (int j0 = 0; j0 < w.tail_split; j0 += 8) {                   // fixed order: deterministic; 16 independent loads in flight per
+        f32x4 a[8], b[8];                                            // thread (one at a time the pass was a chain of round trips)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u < w.tail_split ? j0 + u : j0;       // (re-reads a valid partial; its value is dropped below)
+            a[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)j * (PT * PT)));
+            b[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)j * (PT * PT) + 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u < w.tail_split) {
+                v[0] += a[u][0]; v[1] += a[u][1]; v[2] += a[u][2]; v[3] += a[u][3];
+                v[4] += b[u][0]; v[5] += b[u][1]; v[6] += b[u][2]; v[7] += b[u][3];
+            }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= p.alpha;

@@ -11,7 +11,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 BB = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 shapes = [("mixer self  S=256 H=12", BB, 12, 256, 256, True), ("backbone self S=64 H=16", BB, 16, 64, 64, True),
           ("cross Sq=64 Skv=77 H=16", BB, 16, 64, 77, False), ("caption self S=77 H=16", BB, 16, 77, 77, True),
-          ("mixer cross 256x77 H=12", BB, 12, 256, 77, False)]
+          ("mixer cross 256x77 H=12", BB, 12, 256, 77, False),
+          # res_512_pretrain (64 x 64 latents: 1024 mixer tokens), a 256-image microbatch = BB / 4 samples
+          ("res512 mixer self S=1024", max(1, BB // 4), 12, 1024, 1024, True), ("res512 mixer cross 1024x77", max(1, BB // 4), 12, 1024, 77, False)]
 for name, B, H, Sq, Skv, packed in shapes:
     hd, hid = 64, H * 64
     if packed:

@@ -131,13 +131,16 @@ def _attn_ref(q, k, v, H, hd):
                                                     (2, 16, 64, 77, 64, False), (2, 3, 77, 77, 64, True),
                                                     (4, 8, 256, 256, 32, True), (2, 4, 40, 77, 32, False),
                                                     (1, 2, 1024, 1024, 64, True), (2, 12, 256, 77, 64, False),
-                                                    (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True)])
+                                                    (3, 2, 96, 200, 64, False), (2, 2, 16, 16, 32, True),
+                                                    (2, 3, 1024, 77, 64, False),      # res-512 mixer cross-attention: 4 query blocks x 1 key block
+                                                    (1, 2, 600, 300, 64, False),      # ragged 3 x 2 block grid (idle workgroups in a round)
+                                                    (1, 2, 300, 700, 32, False)])     # more key blocks than query blocks, head_dim 32
 @pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4])
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
-    """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256); 1: the dQ + dK/dV
-    kernel pair (the only path for longer sequences); 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in
-    LDS together) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4)) form, all
-    for Sq, Skv <= 256 --
+    """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256; longer sequences --
+    the res-512 mixer, 1024 tokens -- as Latin-square rounds of <= 256 x 256 block pairs on the two-phase fused kernel); 1: the
+    dQ + dK/dV kernel pair; 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in LDS together; Sq, Skv <= 256
+    only) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4); any length) form --
     a forced form that does not cover the problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of
     the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
@@ -172,7 +175,7 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    covered = bwd_split in (0, 1) or max(Sq, Skv) <= 256
+    covered = bwd_split != 2 or max(Sq, Skv) <= 256
     rc = L.md_attn_bwd(byref(a), st)
     if not covered:
         torch.cuda.synchronize()
