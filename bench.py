@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-other-stages", action="store_true", help="skip the res_256_finetune / res_512_pretrain / microbatch-256 legs")
-    ap.add_argument("--attn-bwd", default="auto", choices=["auto", "pair", "fused1", "fused2", "fused2s"],
+    ap.add_argument("--attn-bwd", default="auto", choices=["auto", "pair", "fused1", "fused2", "fused2s", "stream"],
                     help="A/B runs: force one attention-backward kernel wherever it covers the shape (default: the library's rule)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rank-probe", action="store_true", help=argparse.SUPPRESS)   # tests: every rank reports itself and exits (no GPU needed)
@@ -304,7 +304,7 @@ def main():
     head = Stage("res_256_pretrain", args.arch, args.global_batch, args.microbatch, world, rank)
     head.trainer.measure_comm = world > 1
     if args.attn_bwd != "auto":
-        head.model.dit.engine.attn_bwd_prefer = {"pair": 1, "fused1": 2, "fused2": 3, "fused2s": 4}[args.attn_bwd]
+        head.model.dit.engine.attn_bwd_prefer = {"pair": 1, "fused1": 2, "fused2": 3, "fused2s": 4, "stream": 5}[args.attn_bwd]
     elapsed, loss = head.timed(args.steps, args.warmup, world)
     ms_per_step = elapsed / args.steps * 1e3
     value = args.global_batch * args.steps / elapsed

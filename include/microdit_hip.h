@@ -202,13 +202,15 @@ typedef struct md_attn_args {
     int64_t lddq, lddk, lddv, lddo, sdq, sdk, sdv, sdo;
     float scale;
     int32_t hd;        /* 32 or 64 */
-    int32_t bwd_split; /* backward kernel: 0 = the library picks (one fused launch per (batch, head) for Sq, Skv <= 256; longer
-                          sequences as max(ceil(Sq / 256), ceil(Skv / 256)) rounds of <= 256 x 256 block pairs on the two-phase
-                          fused kernel, each output block with one writer per round, dq / dk / dv accumulated in place);
+    int32_t bwd_split; /* backward kernel: 0 = the library picks (one fused launch per (batch, head) for Sq, Skv <= 256; the streaming
+                          pair (5) for longer sequences);
                           forced (tests, A/B runs): 1 = the dQ + dK/dV pair, 2 = fused with Q, dO, K, V in LDS together (Sq, Skv
-                          <= 256 only), 3 = fused in two phases on half the LDS, 4 = the same with dK / dV as two passes for every
-                          size (3 does that for the 256-row buckets only).  A forced variant that does not cover the problem
-                          returns -1 and launches nothing. */
+                          <= 256 only), 3 = fused in two phases on half the LDS (longer sequences: one launch per <= 256 x 256 block
+                          pair, every output block with one writer at a time, dq / dk / dv accumulated in place), 4 = the same with
+                          dK / dV as two passes for every
+                          size (3 does that for the 256-row buckets only), 5 = the streaming pair (the pair's two launches with
+                          128-row chunks, register prefetch and 8-wave workgroups: the library's choice when Sq or Skv > 256).
+                          A forced variant that does not cover the problem returns -1 and launches nothing. */
 } md_attn_args;
 
 int md_attn_fwd(const md_attn_args* a, hipStream_t stream);

@@ -10,6 +10,7 @@
 //   Operands that are needed transposed (V^T, K^T, Q^T, dO^T) are read from the row-major LDS tile with
 //   ds_read_b64_tr_b16, so nothing is transposed through memory.
 // Replaces F.scaled_dot_product_attention (utils.py:127-132, 188-193) and its autograd backward.
+#include <stdlib.h>
 #include "md_common.h"
 #include "../../include/microdit_hip.h"
 
@@ -423,6 +424,246 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
             }
         }
       }
+    }
+    if (kvalid) {
+        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
+        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+        store_rows<HD>(dK, dkacc, p.scale, lane);
+        store_rows<HD>(dV, dvacc, 1.f, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming pair for LONG sequences (Sq or Skv > 256: the res-512 patch mixer, 1024 tokens, and its 1024 x 77 cross-attention;
+// /root/reference/configs/res_512_pretrain.yaml:24, utils.py:188-193).  Same arithmetic and the same two launches as the pair above
+// (dQ: every wave owns 32 query rows and walks the keys; dK / dV: every wave owns 32 key rows and walks the queries), re-organised
+// around what the 32-row phases cost there -- a global -> LDS round trip with nothing in flight under each phase's 12-16 MFMAs:
+//   * the walked side arrives in CHUNKS of SCH rows (128 for workgroups of 5-8 waves: 4 tiles per barrier pair instead of 1; 64 / 32
+//     for smaller workgroups, so that a thread never stages more than 4 x 16 bytes per matrix -- the staging registers are what
+//     the dK / dV kernel, with its four accumulators, has least of);
+//   * chunk c + 1 is requested into registers right after chunk c has been written to LDS and lands while chunk c is being
+//     multiplied (the compiler's waits for those registers sit at the next LDS write, not in the tile loop: MFMA and ds_read do
+//     not depend on them);
+//   * workgroups of up to 8 waves (256 owned rows), so a chunk is fetched once per 256 rows instead of once per 128.
+// The dK / dV kernel also prefetches the chunk's log-sum-exp / delta values (one float each per row).
+// ---------------------------------------------------------------------------------------------------------------------
+
+template <int HD, int MAXIT>
+struct ChunkRegs {
+    u32x4 a[MAXIT], b[MAXIT];
+};
+// global -> registers: rows row0 .. row0 + SCH of A and B (rows >= nrows: zeros); every load of the chunk in flight at once
+template <int HD, int SCH, int MAXIT>
+__device__ __forceinline__ void chunk_load(ChunkRegs<HD, MAXIT>& R, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, int64_t row0,
+                                           int64_t nrows, int tid, int nthreads) {
+    constexpr int CPR = HD / 8;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int task = tid + it * nthreads, r = task / CPR, c = task % CPR;
+        const bool ok = task < SCH * CPR && row0 + r < nrows;
+        R.a[it] = ok ? *reinterpret_cast<const u32x4*>(A + (row0 + r) * lda + c * 8) : z4;
+        R.b[it] = ok ? *reinterpret_cast<const u32x4*>(B + (row0 + r) * ldb + c * 8) : z4;
+    }
+}
+template <int HD, int SCH, int MAXIT>
+__device__ __forceinline__ void chunk_store(const ChunkRegs<HD, MAXIT>& R, unsigned char* tileA, unsigned char* tileB, int pitch, int tid,
+                                            int nthreads) {
+    constexpr int CPR = HD / 8;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int task = tid + it * nthreads, r = task / CPR, c = task % CPR;
+        if (task < SCH * CPR) {
+            *reinterpret_cast<u32x4*>(tileA + r * pitch + c * 16) = R.a[it];
+            *reinterpret_cast<u32x4*>(tileB + r * pitch + c * 16) = R.b[it];
+        }
+    }
+}
+
+template <int HD, int SCH, int MAXIT>
+__global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SCH * PK];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + SCH * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool qvalid = q < p.Sq;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+
+    ChunkRegs<HD, MAXIT> R;
+    chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, 0, p.Skv, tid, nthreads);       // chunk 0 on its way before the row set-up
+    bf16x8 qf[HD / 16], dof[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (qvalid) {
+            qf[s] = ld_bf16x8(Q + q * p.ldq + s * 16 + hh * 8);
+            dof[s] = ld_bf16x8(dO + q * p.lddo + s * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qf[s][e] = f2bf(0.f);
+                dof[s][e] = f2bf(0.f);
+            }
+        }
+    }
+    const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] * LOG2E : 0.f;   // log2 domain (ds_cols)
+    const float c1 = p.scale * LOG2E;
+    float dlt = 0.f;      // delta[q] = sum_d dO[q, d] * O[q, d]: this lane holds half of row q, the partner lane the rest
+    if (qvalid) {
+        const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            const bf16x8 ov = ld_bf16x8(O + s * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt += bf2f(ov[e]) * bf2f(dof[s][e]);
+        }
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (qvalid && lane < 32) reinterpret_cast<float*>(p.delta)[(b * p.H + h) * p.Sq + q] = dlt;   // for the dK / dV kernel
+    f32x16 dqacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
+
+    for (int64_t kbase = 0; kbase < p.Skv; kbase += SCH) {
+        __syncthreads();                                   // every wave is done with the previous chunk's tiles
+        chunk_store<HD, SCH, MAXIT>(R, sK, sV, PK, tid, nthreads);
+        __syncthreads();
+        if (kbase + SCH < p.Skv) chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, kbase + SCH, p.Skv, tid, nthreads);   // lands under the tile loop
+        for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+            const unsigned char* tK = sK + sub * 32 * PK;
+            const unsigned char* tV = sV + sub * 32 * PK;
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
+            }
+            ds_cols(sacc, dpacc, c1, lse, dlt, (int)(p.Skv - kbase - sub * 32), hh);   // dS^T / scale
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(sacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di)
+                    dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+        store_rows<HD>(dQ, dqacc, p.scale, lane);
+    }
+}
+
+template <int HD, int SCH, int MAXIT>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p) {
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SCH * PK + 2 * SCH * 4];
+    unsigned char* sQ = smem;
+    unsigned char* sdO = smem + SCH * PK;
+    float* sLseAll = reinterpret_cast<float*>(smem + 2 * SCH * PK);
+    float* sDltAll = sLseAll + SCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;        // scores -> log2 domain (p_ds_rows)
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t key = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool kvalid = key < p.Skv;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
+    const float* DLT = reinterpret_cast<const float*>(p.delta) + (b * p.H + h) * p.Sq;
+
+    ChunkRegs<HD, MAXIT> R;
+    float rl = 0.f, rd = 0.f;                 // this thread's row of the chunk's log-sum-exp / delta (threads < SCH)
+    chunk_load<HD, SCH, MAXIT>(R, Q, p.ldq, dO, p.lddo, 0, p.Sq, tid, nthreads);
+    if (tid < SCH && tid < p.Sq) {
+        rl = LSE[tid];
+        rd = DLT[tid];
+    }
+    bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (kvalid) {
+            kf[s] = ld_bf16x8(K + key * p.ldk + s * 16 + hh * 8);
+            vf[s] = ld_bf16x8(V + key * p.ldv + s * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kf[s][e] = f2bf(0.f);
+                vf[s][e] = f2bf(0.f);
+            }
+        }
+    }
+    f32x16 dkacc[HD / 32], dvacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkacc[di][r] = 0.f;
+            dvacc[di][r] = 0.f;
+        }
+
+    for (int64_t qbase = 0; qbase < p.Sq; qbase += SCH) {
+        __syncthreads();
+        chunk_store<HD, SCH, MAXIT>(R, sQ, sdO, PK, tid, nthreads);
+        if (tid < SCH) {
+            sLseAll[tid] = rl * LOG2E;          // log2 domain; rows beyond Sq: 0 (masked by `rem` in p_ds_rows)
+            sDltAll[tid] = rd;
+        }
+        __syncthreads();
+        if (qbase + SCH < p.Sq) {
+            chunk_load<HD, SCH, MAXIT>(R, Q, p.ldq, dO, p.lddo, qbase + SCH, p.Sq, tid, nthreads);
+            const int64_t rn = qbase + SCH + tid;
+            const bool ok = tid < SCH && rn < p.Sq;
+            rl = ok ? LSE[rn] : 0.f;
+            rd = ok ? DLT[rn] : 0.f;
+        }
+        for (int sub = 0; sub < SCH / 32 && qbase + sub * 32 < p.Sq; ++sub) {
+            const unsigned char* tQ = sQ + sub * 32 * PK;
+            const unsigned char* tdO = sdO + sub * 32 * PK;
+            const float* tLse = sLseAll + sub * 32;
+            const float* tDlt = sDltAll + sub * 32;
+            f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.f;
+                dpacc[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
+            }
+            p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, (int)(p.Sq - qbase - sub * 32), hh);   // P, dS / scale
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc, 8 * sp);
+                const bf16x8 dsf = pack8(dpacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di) {
+                    dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
+                    dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
+                }
+            }
+        }
     }
     if (kvalid) {
         bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
@@ -1005,6 +1246,38 @@ bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     return true;
 }
 
+// The streaming pair: workgroups of up to 8 waves (MD_ATTN_STREAM_WAVES lowers the cap: A/B runs).
+inline int stream_waves(int64_t S) {
+    static const int cap = [] {
+        const char* e = getenv("MD_ATTN_STREAM_WAVES");
+        const int v = e ? atoi(e) : 8;
+        return v < 2 ? 2 : (v > 8 ? 8 : v);
+    }();
+    const int64_t w = (S + 31) / 32;
+    return (int)(w > cap ? cap : (w < 2 ? 2 : w));     // at least two waves (a second, idle one when S <= 32: the one-wave staging
+}                                                      // loop would need 4 + 4 more staging registers than the dK / dV kernel has)
+template <int HD>
+void launch_bwd_stream(const md_attn_args* a, hipStream_t stream) {
+    const int nwq = stream_waves(a->Sq), nwk = stream_waves(a->Skv);
+    const dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
+    const dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);
+    // (chunk rows, 16-byte pieces per thread and matrix) by workgroup size: 8 waves (128, 2); 6-7 (128, 3); 5 (128, 4);
+    // 4 (64, 2); 3 (64, 3); 2 (64, 4)
+#define STREAM(KERN, GRID, NW)                                                                                       \
+    do {                                                                                                             \
+        const dim3 blk(64 * NW);                                                                                     \
+        if (NW == 8) hipLaunchKernelGGL((KERN<HD, 128, 2>), GRID, blk, 0, stream, *a);                               \
+        else if (NW >= 6) hipLaunchKernelGGL((KERN<HD, 128, 3>), GRID, blk, 0, stream, *a);                          \
+        else if (NW == 5) hipLaunchKernelGGL((KERN<HD, 128, 4>), GRID, blk, 0, stream, *a);                          \
+        else if (NW == 4) hipLaunchKernelGGL((KERN<HD, 64, 2>), GRID, blk, 0, stream, *a);                           \
+        else if (NW == 3) hipLaunchKernelGGL((KERN<HD, 64, 3>), GRID, blk, 0, stream, *a);                           \
+        else hipLaunchKernelGGL((KERN<HD, 64, 4>), GRID, blk, 0, stream, *a);                                        \
+    } while (0)
+    STREAM(attn_bwd_dq_stream_kernel, gq, nwq);      // also writes delta
+    STREAM(attn_bwd_dkv_stream_kernel, gk, nwk);
+#undef STREAM
+}
+
 inline int waves_for(int64_t S) {
     int64_t w = (S + 31) / 32;
     return (int)(w > 4 ? 4 : (w < 1 ? 1 : w));
@@ -1041,7 +1314,14 @@ extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
     // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
-    if (a->bwd_split < 0 || a->bwd_split > 4) return MD_BAD_ARG;
+    if (a->bwd_split < 0 || a->bwd_split > 5) return MD_BAD_ARG;
+    const bool long_seq = a->Sq > 256 || a->Skv > 256;
+    if (a->bwd_split == 5 || (a->bwd_split == 0 && long_seq)) {      // the streaming pair (any size; the library's choice for long sequences)
+        if (a->hd == 64) launch_bwd_stream<64>(a, stream);
+        else launch_bwd_stream<32>(a, stream);
+        MD_LAUNCH_CHECK();
+        return 0;
+    }
     if (a->bwd_split != 1) {
         if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
             MD_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ EPI_STORE_BF16, EPI_RESIDUAL, EPI_STORE_F32, EPI_ACCUM_F32, EPI_ATOMIC_F32, EPI_
 GEMM_AUTO, GEMM_REG128, GEMM_DMA128, GEMM_PACED256, GEMM_PP256 = 0, 1, 2, 3, 4
 GEMM_VARIANT_NAMES = {"auto": 0, "reg128": 1, "dma128": 2, "paced256": 3, "pp256": 4}
 # md_attn_args.bwd_split: backward kernel selector (0 = the library's rule; the others force a kernel: tests, A/B runs)
-ATTN_BWD_AUTO, ATTN_BWD_PAIR, ATTN_BWD_FUSED_1PHASE, ATTN_BWD_FUSED_2PHASE, ATTN_BWD_FUSED_2PHASE_SPLIT = 0, 1, 2, 3, 4
+ATTN_BWD_AUTO, ATTN_BWD_PAIR, ATTN_BWD_FUSED_1PHASE, ATTN_BWD_FUSED_2PHASE, ATTN_BWD_FUSED_2PHASE_SPLIT, ATTN_BWD_STREAM_PAIR = 0, 1, 2, 3, 4, 5
 
 
 def _sources():

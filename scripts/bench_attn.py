@@ -36,7 +36,8 @@ for name, B, H, Sq, Skv, packed in shapes:
     for fn, label, mult, split, byt in ((L.md_attn_fwd, "fwd        ", 4, 0, elt * (2 * Sq + 2 * Skv)), (L.md_attn_bwd, "bwd auto   ", 10, 0, elt * (4 * Sq + 4 * Skv)),
                                         (L.md_attn_bwd, "bwd 1-phase", 10, 2, elt * (4 * Sq + 4 * Skv)), (L.md_attn_bwd, "bwd 2-phase", 10, 3, elt * (4 * Sq + 4 * Skv)),
                                         (L.md_attn_bwd, "bwd 2ph+spl", 10, 4, elt * (4 * Sq + 4 * Skv)),
-                                        (L.md_attn_bwd, "bwd pair   ", 10, 1, elt * (4 * Sq + 4 * Skv))):
+                                        (L.md_attn_bwd, "bwd pair   ", 10, 1, elt * (4 * Sq + 4 * Skv)),
+                                        (L.md_attn_bwd, "bwd stream ", 10, 5, elt * (4 * Sq + 4 * Skv))):
         a.bwd_split = split
         if fn(byref(a), st) == -1:
             continue                      # a forced form that does not cover this shape

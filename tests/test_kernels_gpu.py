@@ -135,12 +135,13 @@ def _attn_ref(q, k, v, H, hd):
                                                     (2, 3, 1024, 77, 64, False),      # res-512 mixer cross-attention: 4 query blocks x 1 key block
                                                     (1, 2, 600, 300, 64, False),      # ragged 3 x 2 block grid (idle workgroups in a round)
                                                     (1, 2, 300, 700, 32, False)])     # more key blocks than query blocks, head_dim 32
-@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4, 5])
 def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256; longer sequences --
-    the res-512 mixer, 1024 tokens -- as Latin-square rounds of <= 256 x 256 block pairs on the two-phase fused kernel); 1: the
+    the res-512 mixer, 1024 tokens -- on the streaming pair); 1: the
     dQ + dK/dV kernel pair; 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in LDS together; Sq, Skv <= 256
-    only) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4); any length) form --
+    only) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4); any length) form;
+    5: the streaming pair (128-row chunks with register prefetch, up to 8 waves per workgroup; the library's choice for long sequences) --
     a forced form that does not cover the problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of
     the same bf16 inputs."""
     torch.manual_seed(B * H + Sq + Skv + hd)
