@@ -537,7 +537,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p)
         chunk_store<HD, SCH, MAXIT>(R, sK, sV, PK, tid, nthreads);
         __syncthreads();
         if (kbase + SCH < p.Skv) chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, kbase + SCH, p.Skv, tid, nthreads);   // lands under the tile loop
-        for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+        auto tile = [&](int sub, int rem) {
             const unsigned char* tK = sK + sub * 32 * PK;
             const unsigned char* tV = sV + sub * 32 * PK;
             f32x16 sacc, dpacc;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p)
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
             }
-            ds_cols(sacc, dpacc, c1, lse, dlt, (int)(p.Skv - kbase - sub * 32), hh);   // dS^T / scale
+            ds_cols(sacc, dpacc, c1, lse, dlt, rem, hh);   // dS^T / scale
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 dsf = pack8(sacc, 8 * sp);
@@ -560,6 +560,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p)
                     dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         tr_frag(tK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
             }
+        };
+        if (kbase + SCH <= p.Skv) {
+            // a whole chunk (every chunk but a ragged last one): no masks, and ONE basic block of SCH / 32 tiles -- the scheduler
+            // can place the next tile's fragment reads and S / dP products under this tile's exponentials
+#pragma unroll
+            for (int sub = 0; sub < SCH / 32; ++sub) tile(sub, 32);
+        } else {
+            for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) tile(sub, (int)(p.Skv - kbase - sub * 32));
         }
     }
     if (qvalid) {
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
             rl = ok ? LSE[rn] : 0.f;
             rd = ok ? DLT[rn] : 0.f;
         }
-        for (int sub = 0; sub < SCH / 32 && qbase + sub * 32 < p.Sq; ++sub) {
+        auto tile = [&](int sub, int rem) {
             const unsigned char* tQ = sQ + sub * 32 * PK;
             const unsigned char* tdO = sdO + sub * 32 * PK;
             const float* tLse = sLseAll + sub * 32;
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
             }
-            p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, (int)(p.Sq - qbase - sub * 32), hh);   // P, dS / scale
+            p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, rem, hh);   // P, dS / scale
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 pf = pack8(sacc, 8 * sp);
@@ -663,7 +671,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
                         tr_frag(tQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
                 }
             }
-        }
+        };
+        // (One copy of the tile body, rolled: a mask-free copy for whole chunks, or two / four tiles per basic block as in the dQ kernel,
+        // pushes this kernel -- four accumulators -- past the 256-register budget: 8-126 spilled registers.)
+        for (int sub = 0; sub < SCH / 32 && qbase + sub * 32 < p.Sq; ++sub) tile(sub, (int)(p.Sq - qbase - sub * 32));
     }
     if (kvalid) {
         bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
@@ -1251,27 +1262,30 @@ inline int stream_waves(int64_t S) {
     static const int cap = [] {
         const char* e = getenv("MD_ATTN_STREAM_WAVES");
         const int v = e ? atoi(e) : 8;
-        return v < 2 ? 2 : (v > 8 ? 8 : v);
+        return v < 3 ? 3 : (v > 8 ? 8 : v);
     }();
-    const int64_t w = (S + 31) / 32;
-    return (int)(w > cap ? cap : (w < 2 ? 2 : w));     // at least two waves (a second, idle one when S <= 32: the one-wave staging
-}                                                      // loop would need 4 + 4 more staging registers than the dK / dV kernel has)
+    int w = (int)((S + 31) / 32 > cap ? cap : (S + 31) / 32);
+    if (w == 5) w = 6;          // workgroup sizes whose staging loop is 2 or 3 pieces per thread and matrix: 8, 7, 6, 4, 3 waves
+    if (w < 3) w = 3;           // (5 or <= 2 waves would need 4: the dK / dV kernel has no registers left for them; the extra waves own
+    return w;                   // rows beyond the sequence and multiply zeros)
+}
 template <int HD>
 void launch_bwd_stream(const md_attn_args* a, hipStream_t stream) {
-    const int nwq = stream_waves(a->Sq), nwk = stream_waves(a->Skv);
+    int nwq = stream_waves(a->Sq), nwk = stream_waves(a->Skv);
+    // a walked side of one chunk (the res-512 cross-attention: 77 keys) has nothing to prefetch: smaller workgroups, more of them
+    // per CU, hide its single round trip better (1024 x 77, 256 samples x 12 heads: 815 us with 4 waves, 912 with 8)
+    if (a->Skv <= 128 && nwq > 4) nwq = 4;
+    if (a->Sq <= 128 && nwk > 4) nwk = 4;
     const dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
     const dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);
-    // (chunk rows, 16-byte pieces per thread and matrix) by workgroup size: 8 waves (128, 2); 6-7 (128, 3); 5 (128, 4);
-    // 4 (64, 2); 3 (64, 3); 2 (64, 4)
+    // (chunk rows, 16-byte pieces per thread and matrix) by workgroup size: 8 waves (128, 2); 6-7 (128, 3); 4 (64, 2); 3 (64, 3)
 #define STREAM(KERN, GRID, NW)                                                                                       \
     do {                                                                                                             \
         const dim3 blk(64 * NW);                                                                                     \
         if (NW == 8) hipLaunchKernelGGL((KERN<HD, 128, 2>), GRID, blk, 0, stream, *a);                               \
         else if (NW >= 6) hipLaunchKernelGGL((KERN<HD, 128, 3>), GRID, blk, 0, stream, *a);                          \
-        else if (NW == 5) hipLaunchKernelGGL((KERN<HD, 128, 4>), GRID, blk, 0, stream, *a);                          \
         else if (NW == 4) hipLaunchKernelGGL((KERN<HD, 64, 2>), GRID, blk, 0, stream, *a);                           \
-        else if (NW == 3) hipLaunchKernelGGL((KERN<HD, 64, 3>), GRID, blk, 0, stream, *a);                           \
-        else hipLaunchKernelGGL((KERN<HD, 64, 4>), GRID, blk, 0, stream, *a);                                        \
+        else hipLaunchKernelGGL((KERN<HD, 64, 3>), GRID, blk, 0, stream, *a);                                        \
     } while (0)
     STREAM(attn_bwd_dq_stream_kernel, gq, nwq);      // also writes delta
     STREAM(attn_bwd_dkv_stream_kernel, gk, nwk);
