@@ -480,8 +480,100 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs<HD, MAXIT>& R, unsig
     }
 }
 
+// Forward for long key sequences on the same plan (chunks of SCH keys, the next chunk's K / V in flight under the current one's
+// tiles, up to 8 waves of 32 query rows): the online-softmax tile loop is attn_fwd_kernel's.
 template <int HD, int SCH, int MAXIT>
-__global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p) {
+__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) {      // (capped at 128 VGPRs it spills 10-50 registers)
+    constexpr int PK = (HD + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SCH * PK];
+    unsigned char* sKc = smem;
+    unsigned char* sVc = smem + SCH * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+    const int hh = lane >> 5;
+    const float c1 = p.scale * LOG2E;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
+    const bool qvalid = q < p.Sq;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+
+    ChunkRegs<HD, MAXIT> R;
+    chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, 0, p.Skv, tid, nthreads);
+    bf16x8 qf[HD / 16];
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+        if (qvalid)
+            qf[s] = ld_bf16x8(Q + q * p.ldq + s * 16 + hh * 8);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = f2bf(0.f);
+    }
+    f32x16 oacc[HD / 32];
+#pragma unroll
+    for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[di][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    for (int64_t kbase = 0; kbase < p.Skv; kbase += SCH) {
+        __syncthreads();
+        chunk_store<HD, SCH, MAXIT>(R, sKc, sVc, PK, tid, nthreads);
+        __syncthreads();
+        if (kbase + SCH < p.Skv) chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, kbase + SCH, p.Skv, tid, nthreads);
+        for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+            const unsigned char* sK = sKc + sub * 32 * PK;
+            const unsigned char* sV = sVc + sub * 32 * PK;
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD / 16; ++s)
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
+            const int rem = (int)(p.Skv - kbase - sub * 32);
+            float tmax = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = tile_slot(r, hh) < rem ? sacc[r] * c1 : -1e30f;
+                tmax = fmaxf(tmax, sacc[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+                sacc[r] = pr;
+                psum += pr;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            l = l * alpha + psum;
+            m = m_new;
+#pragma unroll
+            for (int di = 0; di < HD / 32; ++di)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[di][r] *= alpha;
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc, 8 * sp);
+#pragma unroll
+                for (int di = 0; di < HD / 32; ++di)
+                    oacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(sV, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, oacc[di], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+        store_rows<HD>(O, oacc, 1.f / l, lane);
+        if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = (m + __log2f(l)) * 0.6931471805599453f;   // natural log
+    }
+}
+
+template <int HD, int SCH, int MAXIT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((SCH == 64 && MAXIT == 2) ? 3 : 2)))   // 4-wave form: 168 VGPRs, 3 workgroups / CU
+void attn_bwd_dq_stream_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SCH * PK];
     unsigned char* sK = smem;
@@ -561,9 +653,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(md_attn_args p)
                         tr_frag(tK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
             }
         };
-        if (kbase + SCH <= p.Skv) {
+        if (SCH == 128 && kbase + SCH <= p.Skv) {
             // a whole chunk (every chunk but a ragged last one): no masks, and ONE basic block of SCH / 32 tiles -- the scheduler
-            // can place the next tile's fragment reads and S / dP products under this tile's exponentials
+            // can place the next tile's fragment reads and S / dP products under this tile's exponentials (S = 1024: 4376 -> 4218 us;
+            // costs 64 VGPRs, so the small-workgroup forms -- few keys, latency-bound, 3 waves / SIMD -- keep the rolled loop)
 #pragma unroll
             for (int sub = 0; sub < SCH / 32; ++sub) tile(sub, 32);
         } else {
@@ -1307,6 +1400,22 @@ inline bool attn_ok(const md_attn_args* a) {
 
 extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a)) return MD_BAD_ARG;
+    static const bool fwd_stream = [] { const char* e = getenv("MD_ATTN_FWD_STREAM"); return !e || atoi(e) != 0; }();   // A/B: 0 = the phased kernel everywhere
+    if (fwd_stream && a->Skv > 256 && a->Sq >= 192) {
+        // long key sequences (the res-512 mixer: 1024): chunks of 128 keys with the next chunk in flight, workgroups of 6-8 waves
+        int nw = stream_waves(a->Sq);
+        if (nw < 6) nw = 6;
+        const dim3 grid((unsigned)((a->Sq + 32 * nw - 1) / (32 * nw)), (unsigned)a->H, (unsigned)a->B), blk(64 * nw);
+        if (a->hd == 64) {
+            if (nw == 8) hipLaunchKernelGGL((attn_fwd_stream_kernel<64, 128, 2>), grid, blk, 0, stream, *a);
+            else hipLaunchKernelGGL((attn_fwd_stream_kernel<64, 128, 3>), grid, blk, 0, stream, *a);
+        } else {
+            if (nw == 8) hipLaunchKernelGGL((attn_fwd_stream_kernel<32, 128, 2>), grid, blk, 0, stream, *a);
+            else hipLaunchKernelGGL((attn_fwd_stream_kernel<32, 128, 3>), grid, blk, 0, stream, *a);
+        }
+        MD_LAUNCH_CHECK();
+        return 0;
+    }
     const int nw = waves_for(a->Sq);
     dim3 grid((unsigned)((a->Sq + 32 * nw - 1) / (32 * nw)), (unsigned)a->H, (unsigned)a->B);
     // chunks of a 32-row phase per thread and matrix: 32 * hd / 8 / (64 * nw)
