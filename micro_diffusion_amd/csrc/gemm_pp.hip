@@ -724,10 +724,13 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
 }
 
 // Whole rounds + split-K tail (md_gemm_args.tail_ws).  total = R * G + r items on G workgroups: without the tail the r left-over
-// tiles cost a whole round (one tile time, ~3 us per pair of k-tiles); with it they cost 1 / s of a round plus the raw-tile
-// write and the fix-up launch (~10 us together).  Taken when that is a gain by the model below (tail_mode 0) or whenever the
-// structure allows it (tail_mode 2): bf16-output epilogue, one operand pair, at least one whole round, r <= G / 2, a split
-// s >= 2 that divides the k-loop into whole iterations (two k-tiles) with r * s <= G, and the workspace holds r * s raw tiles.
+// tiles cost a whole round (one tile time, ~3.1 us per pair of k-tiles at the sustained clock); with a split s they cost 1 / s of
+// a round PLUS what the form itself costs: r * s raw 256 KiB tiles written by the main launch and read back by the fix-up
+// (~0.13 us per unit at ~4 TB/s, both directions: measured -- 64 tiles x 4 units made the fix-up a 20 us launch) and the second
+// launch (~6 us with its gap).  The split is the divisor of the k-loop's iteration count that maximises the predicted gain; the
+// form is taken when that gain is > 2 us (tail_mode 0) or whenever the structure allows a split (tail_mode 2: the largest one):
+// bf16-output epilogue, one operand pair, at least one whole round, r <= G / 2, s >= 2 dividing the k-loop into whole iterations
+// (two k-tiles) with r * s <= G, and a workspace that holds r * s raw tiles.
 static bool md_gemm_pp_plan_tail(const md_gemm_args* a, int epi, int cus, PPPlan* w) {
     if (!a->tail_ws || a->tail_mode == 1 || epi == PP_E_F32 || a->A_list || a->problems || a->timeline) return false;
     const int G = cus & ~7;                      // whole tiles are dealt XCD by XCD: every XCD needs the same number of workgroups
@@ -735,14 +738,16 @@ static bool md_gemm_pp_plan_tail(const md_gemm_args* a, int epi, int cus, PPPlan
     const int r = w->total % G;
     if (r == 0 || r * 2 > G) return false;
     const int iters = w->nk >> 1;
+    const double tile_us = 3.1 * iters;
     int s = 0;
-    for (int c = iters; c >= 2; --c)
-        if (iters % c == 0 && (int64_t)r * c <= G) { s = c; break; }
-    if (s < 2 || (int64_t)r * s * (PT * PT * 4) > a->tail_ws_bytes) return false;
-    if (a->tail_mode != 2) {
-        const double tile_us = 3.0 * iters;
-        if (tile_us * (1.0 - 1.0 / s) < 14.0) return false;
+    double best = a->tail_mode == 2 ? -1e30 : 2.0;
+    for (int c = iters; c >= 2; --c) {
+        if (iters % c || (int64_t)r * c > G || (int64_t)r * c * (PT * PT * 4) > a->tail_ws_bytes) continue;
+        if (a->tail_mode == 2) { s = c; break; }                 // forced: the largest split (tests exercise the most units)
+        const double gain = tile_us * (1.0 - 1.0 / c) - (0.13 * r * c + 6.0);
+        if (gain > best) { best = gain; s = c; }
     }
+    if (s < 2) return false;
     w->tail_first = w->total - r;
     w->tail_units = r * s;
     w->tail_split = s;
