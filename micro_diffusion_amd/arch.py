@@ -208,15 +208,33 @@ def sincos_table(dim: int, grid: int, pos_interp_scale: float) -> np.ndarray:
     return np.concatenate(halves, axis=1)
 
 
+def is_block_adaln(name: str) -> bool:
+    """`patch_mixer.<i>.adaLN_modulation.1.{weight,bias}` / `blocks.<i>.adaLN_modulation.1.{weight,bias}` (dit.py:222-225): the
+    modulation Linear of every DiT block reads the SAME input, gelu(c), so the flat layout keeps all their weights (and all their
+    biases) contiguous, in forward order, and the engine computes the modulation of every block with ONE GEMM per forward."""
+    top = name.split(".")
+    return (len(top) == 5 and top[0] in ("blocks", "patch_mixer") and top[1].isdigit() and top[2] == "adaLN_modulation" and top[3] == "1"
+            and top[4] in ("weight", "bias"))
+
+
+def adaln_order(name: str):
+    """Sort key of the block adaLN tensors inside their region: mixer blocks, then backbone blocks, by index (= forward order)."""
+    top = name.split(".")
+    return (0 if top[0] == "patch_mixer" else 1, int(top[1]))
+
+
 def bucket_key(name: str, ndim: int = 2) -> str:
     """Data-parallel bucket a parameter belongs to: one per DiT block ("blocks.17", "patch_mixer.3"), "final_layer", "rest"
     (embedders, caption block, mixer maps) -- the segments whose backward finishes together (engine.backward's on_segment
-    hand-off) -- and "small" for every one-dimensional tensor (biases, LayerNorm weights): those live in one region at the end of
+    hand-off) --, "adaln" (the modulation weights of ALL blocks, first in the flat buffers: complete with the last segment of the
+    backward, needed by the first GEMM after the condition vector in the forward) and "small" for every one-dimensional tensor (biases, LayerNorm weights): those live in one region at the end of
     the flat buffers, are exchanged as one all-reduce and updated by every rank (the engine reads them from the fp32 masters,
     so every replica must hold them exactly; the sharded optimiser step only owns slices of the matrix-shaped buckets)."""
     if ndim <= 1:
         return "small"
     top = name.split(".")
+    if is_block_adaln(name):
+        return "adaln"
     if top[0] in ("blocks", "patch_mixer") and len(top) > 1 and top[1].isdigit():
         return ".".join(top[:2])
     return "final_layer" if top[0] == "final_layer" else "rest"

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .arch import DiTConfig, ParamSpec, bucket_key, param_table, plan_blocks, sincos_table
+from .arch import DiTConfig, ParamSpec, adaln_order, bucket_key, is_block_adaln, param_table, plan_blocks, sincos_table
 from .engine import DiTEngine
 
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the fp32 buffers and 128-byte in the bf16 shadow
@@ -27,13 +27,18 @@ _BUCKET_ALIGN = 1024  # elements; every data-parallel bucket starts (and therefo
 
 def flat_layout(table):
     """Offsets (in elements) of every parameter inside the flat buffers: matrix-shaped tensors in table order (= the reference's
-    registration order, so the tensors of a block are contiguous and [w1; w2] of a SwiGLU stay adjacent), each padded to _ALIGN,
-    a new data-parallel bucket (arch.bucket_key) starting on a multiple of _BUCKET_ALIGN; then all one-dimensional tensors
-    (the "small" bucket) in one region at the end."""
+    registration order, so the tensors of a block are contiguous and [w1; w2] of a SwiGLU stay adjacent; the modulation weights of
+    all blocks first, as one contiguous "adaln" bucket), each padded to _ALIGN, a new data-parallel bucket (arch.bucket_key)
+    starting on a multiple of _BUCKET_ALIGN; then all one-dimensional tensors (the "small" bucket, the block adaLN biases first)
+    in one region at the end."""
     offs, total, prev = {}, 0, None
     for small in (False, True):
-        for spec in table:
-            if spec.buffer or (len(spec.shape) <= 1) != small:
+        # the block adaLN tensors lead their region, contiguous and in forward order (arch.is_block_adaln): ONE [sum 6 d_l, D] matrix
+        # and ONE bias vector for the batched modulation GEMM
+        lead = sorted((s for s in table if not s.buffer and is_block_adaln(s.name)), key=lambda s: adaln_order(s.name))
+        rest = [s for s in table if not s.buffer and not is_block_adaln(s.name)]
+        for spec in lead + rest:
+            if (len(spec.shape) <= 1) != small:
                 continue
             key = bucket_key(spec.name, len(spec.shape))
             if key != prev:

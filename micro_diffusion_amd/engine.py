@@ -134,9 +134,42 @@ class DiTEngine:
         self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
+        self.batch_adaln = True     # the modulation of ALL blocks from one GEMM per forward (A/B: False = one small GEMM per block)
+        self._adaln = self._adaln_region()
         self.gemm_tail_mode = int(os.environ.get("MD_GEMM_TAIL", "0"))   # md_gemm_args.tail_mode: 0 = the library decides, 1 = never, 2 = always (A/B)
         self.cu_limit_fn = None     # data parallelism: callable() -> CUs the persistent GEMM may occupy right now (0 = all): the
         #                             Trainer leaves the CUs of RCCL's channels free while a collective is in flight
+
+    def _adaln_region(self):
+        """The block adaLN Linear layers (dit.py:222-225: mod_l = W_l gelu(c) + b_l, the same input for every block) as ONE GEMM:
+        dit.flat_layout keeps their weights contiguous in forward order (mixer blocks, then backbone blocks) and their biases
+        likewise, so [W_0; W_1; ...] is a [sum 6 d_l, D] matrix.  Returns {"N", "w", "b", "col": {block name: first column}} or None
+        when the tensors are not laid out that way (a foreign flat layout): the per-block GEMMs remain."""
+        names = [bp.name for bp in self.mixer] + [bp.name for bp in self.backbone]
+        col, n, w0, b0 = {}, 0, None, None
+        for nm in names:
+            w, b = self.S.get(nm + ".adaLN_modulation.1.weight"), self.P.get(nm + ".adaLN_modulation.1.bias")
+            if w is None or b is None or w.dim() != 2 or w.shape[1] != self.cfg.dim:
+                return None
+            if w0 is None:
+                w0, b0 = w, b
+            elif w.data_ptr() != w0.data_ptr() + 2 * n * self.cfg.dim or b.data_ptr() != b0.data_ptr() + 4 * n:
+                return None
+            col[nm] = n
+            n += w.shape[0]
+        if w0 is None or n % 8:
+            return None
+        return {"N": n, "w": w0.data_ptr(), "b": b0.data_ptr(), "col": col}
+
+    def _adaln_all(self, gc, B):
+        """mod_all [B, N_all] bf16 = gelu(c) [W_0; W_1; ...]^T + [b_0; b_1; ...]: 780 output tiles at XL/2 instead of 34 launches
+        of 18-24 tiles each (96 TFLOP/s at microbatch 256, profiles/r3_gemm_shapes_mb256.txt)."""
+        r = self._adaln
+        out = self.empty(B, r["N"])
+        D = self.cfg.dim
+        self._gemm(A=gc.data_ptr(), B=r["w"], C=out.data_ptr(), bias=r["b"], M=B, N=r["N"], K=D, lda=D, ldb=D, ldc=r["N"], batch=1, ksplit=1,
+                   a_kcontig=1, b_kcontig=1, mode=hip.EPI_STORE_BF16, act=0, alpha=1.0)
+        return out
 
     # ------------------------------------------------------------------------------------------ launch helpers
     def _st(self):
@@ -465,27 +498,31 @@ class DiTEngine:
         return dxin
 
     # ------------------------------------------------------------------------------------------ DiT block
-    def _block_fwd(self, bp: BlockPlan, x, ycond, B, S, Lc, gc):
+    def _block_fwd(self, bp: BlockPlan, x, ycond, B, S, Lc, gc, mod_all=None):
         L, st, cfg = self.L, self._st(), self.cfg
         d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
         M, Mc, D = B * S, B * Lc, cfg.dim
         n = bp.name
         t = Tape()
         t.x = x
-        mod = self.empty(B, 6 * d)
-        self.lin_fwd(gc, n + ".adaLN_modulation.1", mod, B, 6 * d, D)
-        mp = mod.data_ptr()
-        t.mod = mod
+        if mod_all is not None:              # this block's columns of the batched modulation GEMM (leading dimension N_all)
+            mod, ldm = mod_all, mod_all.shape[1]
+            mp = mod_all.data_ptr() + 2 * self._adaln["col"][n]
+        else:
+            mod, ldm = self.empty(B, 6 * d), 6 * d
+            self.lin_fwd(gc, n + ".adaLN_modulation.1", mod, B, 6 * d, D)
+            mp = mod.data_ptr()
+        t.mod, t.mp, t.ldm = mod, mp, ldm
         # -- self attention: x1 = x + gate_msa * proj(attn(modulate(LN1(x))))
         t.xm1 = self.empty(M, d)
         t.st1 = self.empty(2, M, dtype=F32)
-        a1 = self.ln_args(x, n + ".norm1", t.xm1, M, d, shift=mp, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
+        a1 = self.ln_args(x, n + ".norm1", t.xm1, M, d, shift=mp, scale=mp + 2 * d, ldmod=ldm, rps=S, mean=t.st1[0], rstd=t.st1[1])
         self.ln_fwd(a1)
         t.sa = Tape()
         o = self._self_attn_fwd(n + ".attn", t.xm1, B, S, d, h, bp.heads, t.sa)
         t.br1 = self.empty(M, d)
         x1 = self.empty(M, d)
-        self.lin_fwd(o, n + ".attn.proj", x1, M, d, h, mode=hip.EPI_RESIDUAL, res=x, gate=mp + 2 * 2 * d, ldg=6 * d, rps=S,
+        self.lin_fwd(o, n + ".attn.proj", x1, M, d, h, mode=hip.EPI_RESIDUAL, res=x, gate=mp + 2 * 2 * d, ldg=ldm, rps=S,
                      C2=t.br1)
         t.x1 = x1
         # -- cross attention: x2 = x1 + proj(attn(q(LN2(x1)), kv(y)))
@@ -511,7 +548,7 @@ class DiTEngine:
         # -- feed-forward: x3 = x2 + gate_mlp * mlp(modulate(LN3(x2)))
         t.xm3 = self.empty(M, d)
         t.st3 = self.empty(2, M, dtype=F32)
-        self.ln_fwd(self.ln_args(x2, n + ".norm3", t.xm3, M, d, shift=mp + 2 * 3 * d, scale=mp + 2 * 4 * d, ldmod=6 * d,
+        self.ln_fwd(self.ln_args(x2, n + ".norm3", t.xm3, M, d, shift=mp + 2 * 3 * d, scale=mp + 2 * 4 * d, ldmod=ldm,
                                  rps=S, mean=t.st3[0], rstd=t.st3[1]))
         x3 = self.empty(M, d)
         t.br3 = self.empty(M, d)
@@ -525,7 +562,7 @@ class DiTEngine:
                 self.lin_fwd(t.xm3, n + ".mlp.w2", t.h12, M, f, d, ldc=2 * f, ooff=f)
             t.a = self.empty(M, f)
             self._prof("swiglu", 6.0 * M * f, lambda: hip.check(L.md_swiglu_fwd(t.h12.data_ptr(), 2 * f, t.a.data_ptr(), f, M, f, st), "swiglu"))
-            self.lin_fwd(t.a, n + ".mlp.w3", x3, M, d, f, mode=hip.EPI_RESIDUAL, res=x2, gate=gate_mlp, ldg=6 * d, rps=S,
+            self.lin_fwd(t.a, n + ".mlp.w3", x3, M, d, f, mode=hip.EPI_RESIDUAL, res=x2, gate=gate_mlp, ldg=ldm, rps=S,
                          C2=t.br3)
         else:
             E = cfg.num_experts
@@ -555,7 +592,7 @@ class DiTEngine:
             self._gemm(A=t.hact.data_ptr(), B=w2.data_ptr(), C=t.h2.data_ptr(), M=Bk, N=d, K=f, lda=f, ldb=d, ldc=d,
                        sA=Bk * f, sB=f * d, sC=Bk * d, batch=E, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_STORE_BF16,
                        act=0, alpha=1.0)
-            hip.check(L.md_moe_combine(t.h2.data_ptr(), t.gval.data_ptr(), t.slot.data_ptr(), x2.data_ptr(), gate_mlp, 6 * d,
+            hip.check(L.md_moe_combine(t.h2.data_ptr(), t.gval.data_ptr(), t.slot.data_ptr(), x2.data_ptr(), gate_mlp, ldm,
                                        t.br3.data_ptr(), x3.data_ptr(), B, S, E, k, d, st), "moe_combine")
         return x3, t
 
@@ -579,14 +616,14 @@ class DiTEngine:
         d, h, hx, f = bp.dim, bp.attn_hidden, bp.xattn_hidden, bp.ffn_hidden
         M, Mc, D = B * S, B * Lc, cfg.dim
         n = bp.name
-        mp = t.mod.data_ptr()
+        mp, ldm = t.mp, t.ldm
         self._wgrad_begin()
         dmod = self.zeros(B, 6 * d)          # fp32 grads of (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp)
         dmp = dmod.data_ptr()
         rpb = self._rows_per_block(M, S)
         # ---------------- feed-forward branch
         dbr3 = self.empty(M, d)
-        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, 6 * d, dbr3.data_ptr(),
+        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br3.data_ptr(), mp + 2 * 5 * d, ldm, dbr3.data_ptr(),
                                                                           dmp + 4 * 5 * d, 6 * d, M, d, S, rpb, st), "gate_bwd"))
         dxm3 = self.empty(M, d)
         if not bp.moe:
@@ -633,7 +670,7 @@ class DiTEngine:
             # gate: dWg[E, d] += dlog^T xm3 ; dxm3 += dlog @ Wg
             self.lin_wgrad(dlog, t.xm3, n + ".mlp.gate", M, E, d, lddy=ldl)
             self.lin_dgrad(dlog, n + ".mlp.gate", dxm3, M, E, d, lddy=ldl, mode=hip.EPI_RESIDUAL, res=dxm3)
-        a3 = self.ln_args(t.x2, n + ".norm3", None, M, d, scale=mp + 2 * 4 * d, ldmod=6 * d, rps=S, mean=t.st3[0], rstd=t.st3[1])
+        a3 = self.ln_args(t.x2, n + ".norm3", None, M, d, scale=mp + 2 * 4 * d, ldmod=ldm, rps=S, mean=t.st3[0], rstd=t.st3[1])
         self.ln_bwd(a3, dxm3, dx, accumulate=True, wname=n + ".norm3", dscale=dmp + 4 * 4 * d, dshift=dmp + 4 * 3 * d, ldg=6 * d)
         # ---------------- cross-attention branch (un-gated, un-modulated)
         self.lin_wgrad(dx, t.o2, n + ".cross_attn.proj", M, d, hx, defer=True)     # dx stays as it is until the flush below
@@ -665,14 +702,14 @@ class DiTEngine:
         self.ln_bwd(a2, dxn2, dx, accumulate=True, wname=n + ".norm2")
         # ---------------- self-attention branch
         dbr1 = self.empty(M, d)
-        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, 6 * d, dbr1.data_ptr(),
+        self._prof("gate_bwd", 6.0 * M * d, lambda: hip.check(L.md_gate_bwd(dx.data_ptr(), t.br1.data_ptr(), mp + 2 * 2 * d, ldm, dbr1.data_ptr(),
                                                                           dmp + 4 * 2 * d, 6 * d, M, d, S, rpb, st), "gate_bwd"))
         self.lin_wgrad(dbr1, t.sa.o, n + ".attn.proj", M, d, h, defer=True)
         do = self.empty(M, h)
         self.lin_dgrad(dbr1, n + ".attn.proj", do, M, d, h)
         dxm1 = self._self_attn_bwd(n + ".attn", t.xm1, do, B, S, d, h, bp.heads, t.sa, defer=True)
         self._wgrad_flush()                  # attn.proj, attn.qkv
-        a1 = self.ln_args(t.x, n + ".norm1", None, M, d, scale=mp + 2 * d, ldmod=6 * d, rps=S, mean=t.st1[0], rstd=t.st1[1])
+        a1 = self.ln_args(t.x, n + ".norm1", None, M, d, scale=mp + 2 * d, ldmod=ldm, rps=S, mean=t.st1[0], rstd=t.st1[1])
         self.ln_bwd(a1, dxm1, dx, accumulate=True, wname=n + ".norm1", dscale=dmp + 4 * d, dshift=dmp, ldg=6 * d)
         self._wgroup = None
         # ---------------- adaLN linear: mod = W gelu(c) + b
@@ -927,10 +964,13 @@ class DiTEngine:
             hip.check(L.md_add_bf16(tok.data_ptr(), posb.data_ptr(), x.data_ptr(), B * T * D, st), "add")
             ym = y2
         tp.ym = ym
+        # ---- the modulation vectors of every block (mixer + backbone) from one GEMM on gelu(c), dit.py:222-225
+        seg("adaln")
+        mod_all = self._adaln_all(gc, B) if (self.batch_adaln and self._adaln is not None) else None
         tp.mixer = []
         for bp in self.mixer:
             seg(bp.name)
-            x, bt = self._block_fwd(bp, x, ym, B, T, Lc, gc)
+            x, bt = self._block_fwd(bp, x, ym, B, T, Lc, gc, mod_all)
             if self._record:
                 tp.mixer.append(bt)
         # ---- masking, dit.py:495-504
@@ -963,7 +1003,7 @@ class DiTEngine:
         tp.blocks = []
         for bp in self.backbone:
             seg(bp.name)
-            x, bt = self._block_fwd(bp, x, y2, B, Tk, Lc, gc)
+            x, bt = self._block_fwd(bp, x, y2, B, Tk, Lc, gc, mod_all)
             if self._record:
                 tp.blocks.append(bt)
         # ---- final layer, dit.py:513

@@ -545,9 +545,10 @@ class GradSync:
             return
         for lo, hi in self.ranges.get(name, []):
             self._exchange(lo, hi)
-        if name == "rest":                # the last segment of a backward: the one-dimensional tensors are complete too
-            for lo, hi in self.ranges.get("small", []):
-                self._exchange(lo, hi)
+        if name == "rest":                # the last segment of a backward: the blocks' modulation weights ("adaln": every block's
+            for key in ("adaln", "small"):    # backward wrote its part) and the one-dimensional tensors are complete too
+                for lo, hi in self.ranges.get(key, []):
+                    self._exchange(lo, hi)
 
     def finish(self) -> int:
         """Wait for every bucket; returns the number of norm partial-sum slots filled (0 = the optimiser takes the norm itself;

@@ -221,6 +221,20 @@ def test_shard_plan_partitions_every_bucket():
         home = [b for b in buckets if b[1] <= o and o + n <= b[2]]
         assert len(home) == 1 and home[0][0] == key, (spec.name, key, home)
         assert (len(spec.shape) <= 1) == (key == "small")
+    # the modulation Linear of every block: one contiguous [sum 6 d_l, D] matrix at the head of the flat buffers (bucket "adaln"),
+    # mixer blocks first, then backbone blocks, and their biases contiguous in the same order at the head of the "small" region --
+    # the engine's batched adaLN GEMM (DiTEngine._adaln_region) reads them as one operand
+    from micro_diffusion_amd.arch import plan_blocks
+    mixer, backbone = plan_blocks(m.config)
+    assert buckets[0][0] == "adaln" and buckets[0][1] == 0
+    shapes = {s.name: s.shape for s in m._table}
+    for suffix, first in ((".adaLN_modulation.1.weight", 0), (".adaLN_modulation.1.bias", buckets[-1][1])):
+        nxt = first
+        for bp in list(mixer) + list(backbone):
+            nm = bp.name + suffix
+            assert offs[nm] == nxt, (nm, offs[nm], nxt)
+            nxt += int(np.prod(shapes[nm]))
+    assert buckets[0][2] >= sum(int(np.prod(shapes[bp.name + ".adaLN_modulation.1.weight"])) for bp in list(mixer) + list(backbone))
     w1 = next(s for s in m._table if s.name == "blocks.4.mlp.w1.weight")
     assert offs["blocks.4.mlp.w2.weight"] == offs["blocks.4.mlp.w1.weight"] + int(np.prod(w1.shape))
     for world in (1, 2, 4, 8, 16):

@@ -398,6 +398,33 @@ def test_grouped_deferred_dgrads_equal_per_layer(hip):
         assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-12, k
 
 
+def test_batched_adaln_equals_per_block(hip):
+    """The modulation vectors of ALL blocks from one GEMM on gelu(c) over the contiguous [W_0; W_1; ...] region of the flat layout
+    (DiTEngine._adaln_all; /root/reference/micro_diffusion/models/dit.py:222-239 computes them block by block) against one GEMM per
+    block: same loss, same gradients (the GEMM kernel may differ between the two forms, so not bit-identical), fewer launches."""
+    cfg = orc.tiny_config()
+    sd = orc.dezero_state_dict(orc.synth_state_dict(cfg, 41))
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 42)
+    gb = {k: t.cuda() for k, t in batch.items()}
+    noise = (rnd.cuda(), epsn.cuda(), mnoise.cuda())
+    out = {}
+    for batched in (True, False):
+        m = _product(cfg, sd)
+        assert m.dit.engine._adaln is not None, "the flat layout must keep the block adaLN weights / biases contiguous"
+        m.dit.engine.batch_adaln = batched
+        m.dit.engine.gemm_log = []
+        m._noise_fn = lambda b: noise
+        loss = m.train_microbatch(gb)
+        torch.cuda.synchronize()
+        out[batched] = (float(loss), {k: p.grad.clone() for k, p in m.dit.named_parameters()}, len(m.dit.engine.gemm_log))
+    nblk = len(m.dit.engine.mixer) + len(m.dit.engine.backbone)
+    assert out[False][2] - out[True][2] == nblk - 1, (out[True][2], out[False][2], nblk)
+    assert abs(out[True][0] - out[False][0]) <= 2e-3 * abs(out[False][0])
+    for k in out[True][1]:
+        a, b = out[True][1][k].double(), out[False][1][k].double()
+        assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-12, k
+
+
 def test_ema_weights_are_the_ones_evaluated(hip):
     """train.evaluate swaps the EMA weights in: with smoothing 0 the EMA equals the current weights and the eval loss
     is unchanged; with a frozen EMA (smoothing 1 after the first EMA batch) the eval loss is the loss of the OLD weights."""
