@@ -124,6 +124,38 @@ __device__ __forceinline__ void p_ds_rows(f32x16& s, f32x16& dp, float c1, const
         if (WANT_P) s[r] = pr;
     }
 }
+// The same without the row mask and with the per-row values fetched as four 16-byte LDS reads each (the 16 query rows of a lane are
+// four runs of four: rows 8 j + 4 hh + e): for callers that stage log2-domain log-sum-exp values of ROWS BEYOND THE SEQUENCE as
+// LSE_MASKED (exp2(s c1 - 1e30) = 0: P = dS = 0 there with no compare / select).  Per 32 x 32 tile the masked form issues 32
+// ds_read_b32 + 16 compares + 16 selects that this one does not (round 5: the long-sequence kernels are VALU / LDS-issue bound).
+constexpr float LSE_MASKED = 1e30f;
+template <bool WANT_P, bool WANT_DS, bool VEC = true>
+__device__ __forceinline__ void p_ds_rows_nomask(f32x16& s, f32x16& dp, float c1, const float* tL2, const float* tDlt, int hh) {
+    if (!VEC) {      // one value per read (tried on the capped two-phase fused kernels, which have no registers for the 16-byte form:
+                     // they spill 8-14 registers with it and 10 even with this form, so they keep the masked p_ds_rows)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = tile_slot(r, hh);
+            const float pr = __builtin_amdgcn_exp2f(s[r] * c1 - tL2[ql]);
+            if (WANT_DS) dp[r] = pr * (dp[r] - tDlt[ql]);
+            if (WANT_P) s[r] = pr;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(tL2 + 8 * j + 4 * hh);
+        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+        if (WANT_DS) d4 = *reinterpret_cast<const f32x4*>(tDlt + 8 * j + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const float pr = __builtin_amdgcn_exp2f(s[r] * c1 - l4[e]);
+            if (WANT_DS) dp[r] = pr * (dp[r] - d4[e]);
+            if (WANT_P) s[r] = pr;
+        }
+    }
+}
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
     bf16x8 o;
@@ -521,7 +553,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) { 
         chunk_store<HD, SCH, MAXIT>(R, sKc, sVc, PK, tid, nthreads);
         __syncthreads();
         if (kbase + SCH < p.Skv) chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, kbase + SCH, p.Skv, tid, nthreads);
-        for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) {
+        auto tile = [&](int sub, int rem) {
             const unsigned char* sK = sKc + sub * 32 * PK;
             const unsigned char* sV = sVc + sub * 32 * PK;
             f32x16 sacc;
@@ -530,7 +562,6 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) { 
 #pragma unroll
             for (int s = 0; s < HD / 16; ++s)
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
-            const int rem = (int)(p.Skv - kbase - sub * 32);
             float tmax = -1e30f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -562,6 +593,12 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) { 
                     oacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         tr_frag(sV, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, oacc[di], 0, 0, 0);
             }
+        };
+        if (kbase + SCH <= p.Skv) {            // a whole chunk: the key mask folds away (rem = 32 is a constant)
+#pragma unroll 1
+            for (int sub = 0; sub < SCH / 32; ++sub) tile(sub, 32);
+        } else {
+            for (int sub = 0; sub < SCH / 32 && kbase + sub * 32 < p.Skv; ++sub) tile(sub, (int)(p.Skv - kbase - sub * 32));
         }
     }
     if (qvalid) {
@@ -693,9 +730,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
     ChunkRegs<HD, MAXIT> R;
     float rl = 0.f, rd = 0.f;                 // this thread's row of the chunk's log-sum-exp / delta (threads < SCH)
     chunk_load<HD, SCH, MAXIT>(R, Q, p.ldq, dO, p.lddo, 0, p.Sq, tid, nthreads);
-    if (tid < SCH && tid < p.Sq) {
-        rl = LSE[tid];
-        rd = DLT[tid];
+    if (tid < SCH) {
+        rl = tid < p.Sq ? LSE[tid] * LOG2E : LSE_MASKED;
+        rd = tid < p.Sq ? DLT[tid] : 0.f;
     }
     bf16x8 kf[HD / 16], vf[HD / 16];
 #pragma unroll
@@ -724,7 +761,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
         __syncthreads();
         chunk_store<HD, SCH, MAXIT>(R, sQ, sdO, PK, tid, nthreads);
         if (tid < SCH) {
-            sLseAll[tid] = rl * LOG2E;          // log2 domain; rows beyond Sq: 0 (masked by `rem` in p_ds_rows)
+            sLseAll[tid] = rl;                  // log2 domain; rows beyond Sq: LSE_MASKED (p_ds_rows_nomask: P = dS = 0 there)
             sDltAll[tid] = rd;
         }
         __syncthreads();
@@ -732,7 +769,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
             chunk_load<HD, SCH, MAXIT>(R, Q, p.ldq, dO, p.lddo, qbase + SCH, p.Sq, tid, nthreads);
             const int64_t rn = qbase + SCH + tid;
             const bool ok = tid < SCH && rn < p.Sq;
-            rl = ok ? LSE[rn] : 0.f;
+            rl = ok ? LSE[rn] * LOG2E : LSE_MASKED;
             rd = ok ? DLT[rn] : 0.f;
         }
         auto tile = [&](int sub, int rem) {
@@ -751,7 +788,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
             }
-            p_ds_rows<true, true>(sacc, dpacc, c1, tLse, tDlt, rem, hh);   // P, dS / scale
+            (void)rem;
+            p_ds_rows_nomask<true, true>(sacc, dpacc, c1, tLse, tDlt, hh);   // P, dS / scale (rows beyond Sq: staged as LSE_MASKED)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const bf16x8 pf = pack8(sacc, 8 * sp);

@@ -246,8 +246,8 @@ def test_cu_limit_under_a_resident_collective(hip):
     t_free = _time_us(lambda: hip.gemm(**kw), reps=4)
     res = {}
     for name, lim in (("full", 0), ("limited", 248)):
-        best = 1e30
-        for _ in range(5):
+        times = []
+        for _ in range(7):
             torch.cuda.synchronize()
             with torch.cuda.stream(side):            # the hog is resident for 2 ms: far longer than one GEMM launch
                 hip.check(probes.lib().mdp_cu_hog(8, 2000, scratch.data_ptr(), side.cuda_stream), "hog")
@@ -257,11 +257,15 @@ def test_cu_limit_under_a_resident_collective(hip):
             hip.gemm(cu_limit=lim, **kw)
             e1.record()
             torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) * 1e3)
-        res[name] = best
+            times.append(e0.elapsed_time(e1) * 1e3)
+        # the MEDIAN: a trial in which the hog was not resident yet measures the free chip, and the minimum would pick exactly
+        # those trials (round 5: "full" 121 us = the free-chip time, against 195 us with the CUs really held)
+        res[name] = sorted(times)[len(times) // 2]
     print(f"cu_limit under 8 held CUs: free chip {t_free:.1f} us | full grid {res['full']:.1f} us | 248 workgroups {res['limited']:.1f} us")
     import json, os
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/cu_limit_under_hog.json", "w") as fh:
         json.dump({"shape": [M, N, K], "held_cus": 8, "free_chip_us": t_free, "full_grid_us": res["full"], "limited_248_us": res["limited"]}, fh)
+    if res["full"] < 1.1 * t_free:
+        pytest.skip(f"the hog kernel did not hold its CUs while the GEMM ran (full grid {res['full']:.1f} us ~ free chip {t_free:.1f} us): nothing to compare")
     assert res["limited"] <= 1.05 * res["full"], res
