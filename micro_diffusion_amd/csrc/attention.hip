@@ -1439,7 +1439,8 @@ inline bool attn_ok(const md_attn_args* a) {
 extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
     if (!attn_ok(a)) return MD_BAD_ARG;
     static const bool fwd_stream = [] { const char* e = getenv("MD_ATTN_FWD_STREAM"); return !e || atoi(e) != 0; }();   // A/B: 0 = the phased kernel everywhere
-    if (fwd_stream && a->Skv > 256 && a->Sq >= 192) {
+    static const int fwd_stream_min = [] { const char* e = getenv("MD_ATTN_FWD_STREAM_MIN_SKV"); return e ? atoi(e) : 257; }();   // A/B
+    if (fwd_stream && a->Skv >= fwd_stream_min && a->Sq >= 192) {
         // long key sequences (the res-512 mixer: 1024): chunks of 128 keys with the next chunk in flight, workgroups of 6-8 waves
         int nw = stream_waves(a->Sq);
         if (nw < 6) nw = 6;
