@@ -117,6 +117,12 @@ typedef struct md_gemm_args {
     int64_t tail_ws_bytes;
     int32_t tail_mode;
     int32_t* tail_used; /* optional HOST pointer: receives units per left-over tile (s) when the tail form was launched, else 0 */
+    /* Activation derivative cached by the forward (MD_ACT_GELU_ERF only; the expert-choice MoE of dit.py:124,131-142, whose
+     * pre-activation is needed by NOTHING but gelu' in the backward).  MD_EPI_STORE_BF16 with C2: C2 receives
+     * bf16(gelu'(bf16(alpha*acc + bias))) instead of the pre-activation (the forward epilogue has Phi and the density in registers
+     * anyway: +2 operations per pair).  MD_EPI_DACT: aux already holds the derivative, C = bf16(bf16(alpha*acc) * aux) -- the
+     * backward epilogue loses its transcendental and its polynomial.  0 = the plain forms above. */
+    int32_t dact_cached;
 } md_gemm_args;
 
 /* Kernels behind md_gemm_bf16.  AUTO applies the measured per-shape rules; a kernel that cannot

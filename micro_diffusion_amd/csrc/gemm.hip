@@ -225,10 +225,11 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bv[e];
             if (mode == MD_EPI_STORE_BF16 || mode == MD_EPI_RESIDUAL) {
-                if (p.C2) {  // raw (pre-activation / pre-gate) copy for the backward pass
+                if (p.C2) {  // raw (pre-activation / pre-gate) copy for the backward pass -- or, with dact_cached, the activation's derivative
                     bf16x8 o;
+                    const bool cache = mode == MD_EPI_STORE_BF16 && p.dact_cached && p.act == MD_ACT_GELU_ERF;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = cache ? f2bf(apply_dact(bf2f(f2bf(v[e])), p.act)) : f2bf(v[e]);
                     st_bf16x8(reinterpret_cast<bf16*>(p.C2) + (int64_t)batch * p.sC2 + gr * p.ldc2 + gc, o);
                 }
                 if (mode == MD_EPI_STORE_BF16) {
@@ -255,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(const md_gemm_args& p, f32x16 (&ac
                 const bf16x8 ax = pre[mi & 1][it];
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] * apply_dact(bf2f(ax[e]), p.act));
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] * (p.dact_cached ? bf2f(ax[e]) : apply_dact(bf2f(ax[e]), p.act)));
                 st_bf16x8(reinterpret_cast<bf16*>(p.C) + (int64_t)batch * p.sC + gr * p.ldc + gc, o);
             } else {
                 float* cp = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.sC + (int64_t)split * p.sSplit + gr * p.ldc + gc;

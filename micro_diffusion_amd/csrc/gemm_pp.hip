@@ -38,6 +38,9 @@
 
 namespace {
 
+constexpr bool pp_is_dact(int epi) { return epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL; }
+constexpr bool pp_is_gelu(int epi) { return epi == PP_E_BF16_GELU || epi == PP_E_BF16_GELU_D; }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Epilogue of one 64 x 32 quadrant (2 row-fragments of 32 x 32) of one wave.
 // After the operand swap a lane holds C[row = lane & 31][8 g + 4 hi + e] in acc[4 g + e] (hi = lane >> 5); swapping the
@@ -48,7 +51,7 @@ namespace {
 template <int EPI>
 __device__ __forceinline__ int epi_prefetch_count(const md_gemm_args& p) {
     if (EPI == PP_E_RES) return p.gate ? 5 : 4;
-    if (EPI == PP_E_DACT_GELU) return 4;
+    if (pp_is_dact(EPI)) return 4;
     return 0;
 }
 
@@ -150,7 +153,7 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
         quad_rows(l, [&](int i, int g, float (&v)[4]) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = PLAIN ? acc[i][4 * g + e] : acc[i][4 * g + e] * alpha;
-            if (!PLAIN && EPI != PP_E_DACT_GELU && p.bias) {            // rare (MicroDiT's large layers have no bias): plain loads
+            if (!PLAIN && !pp_is_dact(EPI) && p.bias) {            // rare (MicroDiT's large layers have no bias): plain loads
                 const int cb = el.wcol + JH * 128 + 8 * g + 4 * (l >> 5);
                 if (cb < nlim) {
                     const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + (int64_t)et.batch * p.sBias + et.n0 + cb);
@@ -169,9 +172,32 @@ __device__ __forceinline__ void epi_quadrant(const md_gemm_args& p, const PPPlan
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bool ok = PLAIN || (cok && rq + t < mlim);
-            if (EPI != PP_E_DACT_GELU && et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + (size_t)t * ((unsigned)p.ldc2 * 2u) + off2) = T[t];
+            if (!pp_is_dact(EPI) && EPI != PP_E_BF16_GELU_D && et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + (size_t)t * ((unsigned)p.ldc2 * 2u) + off2) = T[t];
             uint4 out = T[t];
-            if constexpr (EPI == PP_E_BF16_GELU) {
+            if constexpr (EPI == PP_E_BF16_GELU_D) {        // C = gelu, C2 = gelu' (the backward multiplies by it: md_gemm_args.dact_cached)
+                float v[8], dv[8];
+                unpack8(T[t], v);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 g2, d2;
+                    gelu_dgelu_erf_2(f32x2{v[e], v[e + 1]}, g2, d2);
+                    v[e] = g2.x;
+                    v[e + 1] = g2.y;
+                    dv[e] = d2.x;
+                    dv[e + 1] = d2.y;
+                }
+                out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+                if (et.c2base && ok)
+                    *reinterpret_cast<uint4*>(et.c2base + (size_t)t * ((unsigned)p.ldc2 * 2u) + off2) =
+                        make_uint4(cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3]), cvt_pk_bf16(dv[4], dv[5]), cvt_pk_bf16(dv[6], dv[7]));
+            } else if constexpr (EPI == PP_E_DACT_MUL) {
+                float v[8], ax[8];
+                unpack8(T[t], v);
+                unpack8(landed(pre[t]), ax);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= ax[e];
+                out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+            } else if constexpr (EPI == PP_E_BF16_GELU) {
                 float v[8];
                 unpack8(T[t], v);
 #pragma unroll
@@ -231,11 +257,11 @@ __device__ __forceinline__ void epi_open(const md_gemm_args& p, const PPPlan& w,
         return;
     }
     et.cbase = const_cast<char*>(tile_base(p.C, (int64_t)et.batch * p.sC + (F32OUT ? (int64_t)et.split * p.sSplit : 0), et, p.ldc, F32OUT ? 4 : 2));
-    et.c2base = (!F32OUT && EPI != PP_E_DACT_GELU && p.C2) ? const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2)) : nullptr;
-    et.opbase = EPI == PP_E_RES        ? tile_base(p.res, 0, et, p.ldr, 2)
-                : EPI == PP_E_DACT_GELU ? tile_base(p.aux, (int64_t)et.batch * p.sAux, et, p.ldaux, 2)
-                                        : nullptr;
-    et.plain = !(EPI != PP_E_DACT_GELU && p.bias) && p.alpha == 1.f && et.m0 + PT <= w.M && et.n0 + PT <= w.N;
+    et.c2base = (!F32OUT && !pp_is_dact(EPI) && p.C2) ? const_cast<char*>(tile_base(p.C2, (int64_t)et.batch * p.sC2, et, p.ldc2, 2)) : nullptr;
+    et.opbase = EPI == PP_E_RES   ? tile_base(p.res, 0, et, p.ldr, 2)
+                : pp_is_dact(EPI) ? tile_base(p.aux, (int64_t)et.batch * p.sAux, et, p.ldaux, 2)
+                                  : nullptr;
+    et.plain = !(!pp_is_dact(EPI) && p.bias) && p.alpha == 1.f && et.m0 + PT <= w.M && et.n0 + PT <= w.N;
     et.gbase = (EPI == PP_E_RES && p.gate) ? reinterpret_cast<const char*>(p.gate) + (size_t)et.n0 * 2 : nullptr;
 }
 
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(md_gemm_args p, PPPla
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the epilogues with prefetched operands are built in the PLAIN form only (two copies of their quadrant body do not fit
     // the register budget); md_gemm_pp_eligible sends their ragged / biased / scaled problems to the gemm.hip kernels
-    constexpr bool PLAIN_ONLY = EPI == PP_E_RES || EPI == PP_E_DACT_GELU;
+    constexpr bool PLAIN_ONLY = EPI == PP_E_RES || pp_is_dact(EPI);
     const int npf = epi_prefetch_count<EPI>(p);
     const bool has_ops = npf > 0;
     u32x4 pre[5];
@@ -637,16 +663,39 @@ __global__ __launch_bounds__(256) void pp_tail_fixup_kernel(md_gemm_args p, PPPl
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= p.alpha;
-    if (EPI != PP_E_DACT_GELU && p.bias) {
+    if (!pp_is_dact(EPI) && p.bias) {
         const float* bp = reinterpret_cast<const float*>(p.bias) + (int64_t)batch * p.sBias + gc;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += bp[i];
     }
     const uint4 T = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
-    if (EPI != PP_E_DACT_GELU && p.C2)
+    if (!pp_is_dact(EPI) && EPI != PP_E_BF16_GELU_D && p.C2)
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (int64_t)batch * p.sC2 + (int64_t)gr * p.ldc2 + gc) = T;
     uint4 out = T;
-    if constexpr (EPI == PP_E_BF16_GELU) {
+    if constexpr (EPI == PP_E_BF16_GELU_D) {
+        float y[8], dy[8];
+        unpack8(T, y);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 g2, d2;
+            gelu_dgelu_erf_2(f32x2{y[i], y[i + 1]}, g2, d2);
+            y[i] = g2.x;
+            y[i + 1] = g2.y;
+            dy[i] = d2.x;
+            dy[i + 1] = d2.y;
+        }
+        out = make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
+        if (p.C2)
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (int64_t)batch * p.sC2 + (int64_t)gr * p.ldc2 + gc) =
+                make_uint4(cvt_pk_bf16(dy[0], dy[1]), cvt_pk_bf16(dy[2], dy[3]), cvt_pk_bf16(dy[4], dy[5]), cvt_pk_bf16(dy[6], dy[7]));
+    } else if constexpr (EPI == PP_E_DACT_MUL) {
+        float y[8], ax[8];
+        unpack8(T, y);
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.aux) + (int64_t)batch * p.sAux + (int64_t)gr * p.ldaux + gc), ax);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= ax[i];
+        out = make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
+    } else if constexpr (EPI == PP_E_BF16_GELU) {
         float y[8];
         unpack8(T, y);
 #pragma unroll
@@ -689,8 +738,8 @@ __global__ __launch_bounds__(256) void pp_tail_fixup_kernel(md_gemm_args p, PPPl
 //   NT (activations x torch weights): bf16, residual, dact(gelu)   NN (dgrads, MoE experts): bf16, bf16+gelu, residual, f32
 //   TN (weight gradients): f32 slices
 static bool pp_instantiated(int akc, int bkc, int epi) {
-    if (akc && bkc) return epi == PP_E_BF16 || epi == PP_E_RES || epi == PP_E_DACT_GELU;
-    if (akc && !bkc) return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_RES || epi == PP_E_F32;
+    if (akc && bkc) return epi == PP_E_BF16 || epi == PP_E_RES || epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL;
+    if (akc && !bkc) return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_BF16_GELU_D || epi == PP_E_RES || epi == PP_E_F32;
     if (!akc && !bkc) return epi == PP_E_F32;
     return false;
 }
@@ -714,7 +763,7 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     }
     if (a->A_list && a->list_segments > 1 && (kspan % ((int64_t)a->list_segments * 128))) return false;   // whole k-tile pairs per segment
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
-    if ((epi == PP_E_RES || epi == PP_E_DACT_GELU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
+    if ((epi == PP_E_RES || pp_is_dact(epi)) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
         return false;                                            // only the PLAIN form of these two epilogues is built
     if (a->M >= (1 << 30) || a->N >= (1 << 30) || a->K >= (1 << 30)) return false;
     if (a->lda > (1 << 22) || a->ldb > (1 << 22)) return false;  // 32-bit per-lane DMA offsets
@@ -773,10 +822,12 @@ int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
     if (a->a_kcontig && a->b_kcontig) {
         if (epi == PP_E_BF16) PP_LAUNCH(1, 1, PP_E_BF16);
         else if (epi == PP_E_RES) PP_LAUNCH(1, 1, PP_E_RES);
+        else if (epi == PP_E_DACT_MUL) PP_LAUNCH(1, 1, PP_E_DACT_MUL);
         else PP_LAUNCH(1, 1, PP_E_DACT_GELU);
     } else if (a->a_kcontig) {
         if (epi == PP_E_BF16) PP_LAUNCH(1, 0, PP_E_BF16);
         else if (epi == PP_E_BF16_GELU) PP_LAUNCH(1, 0, PP_E_BF16_GELU);
+        else if (epi == PP_E_BF16_GELU_D) PP_LAUNCH(1, 0, PP_E_BF16_GELU_D);
         else if (epi == PP_E_RES) PP_LAUNCH(1, 0, PP_E_RES);
         else PP_LAUNCH(1, 0, PP_E_F32);
     } else {
@@ -790,7 +841,9 @@ int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream) {
 #define PP_FIXUP(E) hipLaunchKernelGGL((pp_tail_fixup_kernel<E>), fgrid, fblock, 0, stream, *a, w)
         if (epi == PP_E_BF16) PP_FIXUP(PP_E_BF16);
         else if (epi == PP_E_BF16_GELU) PP_FIXUP(PP_E_BF16_GELU);
+        else if (epi == PP_E_BF16_GELU_D) PP_FIXUP(PP_E_BF16_GELU_D);
         else if (epi == PP_E_RES) PP_FIXUP(PP_E_RES);
+        else if (epi == PP_E_DACT_MUL) PP_FIXUP(PP_E_DACT_MUL);
         else PP_FIXUP(PP_E_DACT_GELU);
 #undef PP_FIXUP
         MD_LAUNCH_CHECK();

@@ -184,7 +184,9 @@ enum {
     PP_E_BF16_GELU = 1,  // MD_EPI_STORE_BF16, GELU(erf)                (+ bias, + C2: the MoE fc1)
     PP_E_RES = 2,        // MD_EPI_RESIDUAL                             (+ bias, + gate, + C2)
     PP_E_DACT_GELU = 3,  // MD_EPI_DACT through GELU(erf)               (the MoE fc1 dgrad)
-    PP_E_F32 = 4         // MD_EPI_STORE_F32                            (+ bias; split-K slices)
+    PP_E_F32 = 4,        // MD_EPI_STORE_F32                            (+ bias; split-K slices)
+    PP_E_BF16_GELU_D = 5,  // MD_EPI_STORE_BF16, GELU(erf), dact_cached: C2 = gelu'(pre-activation) instead of the pre-activation
+    PP_E_DACT_MUL = 6      // MD_EPI_DACT, dact_cached: C = acc * aux  (aux = the cached derivative)
     // MD_EPI_ACCUM_F32 stays on the gemm.hip kernels: its operand (32 fp32 per lane and quadrant) does not fit beside the
     // fragments, and without the one-phase-ahead prefetch each quadrant would drain the DMA ring.
 };
@@ -348,9 +350,10 @@ __device__ __forceinline__ void quad_rows(int l, F&& block, uint4 (&T)[4]) {
 // ---- host side, shared by the launchers
 inline int md_gemm_pp_epi_kind(const md_gemm_args* a) {
     switch (a->mode) {
-        case MD_EPI_STORE_BF16: return a->act == MD_ACT_NONE ? PP_E_BF16 : a->act == MD_ACT_GELU_ERF ? PP_E_BF16_GELU : -1;
+        case MD_EPI_STORE_BF16:
+            return a->act == MD_ACT_NONE ? PP_E_BF16 : a->act == MD_ACT_GELU_ERF ? ((a->dact_cached && a->C2) ? PP_E_BF16_GELU_D : PP_E_BF16_GELU) : -1;
         case MD_EPI_RESIDUAL: return PP_E_RES;
-        case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? PP_E_DACT_GELU : -1;
+        case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? (a->dact_cached ? PP_E_DACT_MUL : PP_E_DACT_GELU) : -1;
         case MD_EPI_STORE_F32: return PP_E_F32;
         default: return -1;
     }

@@ -158,6 +158,15 @@ __device__ __forceinline__ f32x2 dgelu_erf_2(f32x2 x) {
     const f32x2 r = 1.f - q;
     return f32x2{x.x < 0.f ? q.x : r.x, x.y < 0.f ? q.y : r.y} + (x * 0.3989422804014327f) * e;
 }
+// Both at once (the MoE fc1 forward epilogue with md_gemm_args.dact_cached: the backward multiplies by the stored derivative).
+__device__ __forceinline__ void gelu_dgelu_erf_2(f32x2 x, f32x2& g, f32x2& d) {
+    f32x2 q, e;
+    normal_tail2(x, q, e);
+    const f32x2 r = 1.f - q;
+    const f32x2 cdf = {x.x < 0.f ? q.x : r.x, x.y < 0.f ? q.y : r.y};
+    g = x * cdf;
+    d = cdf + (x * 0.3989422804014327f) * e;
+}
 __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
     float s = fast_rcp(1.f + __expf(-x));

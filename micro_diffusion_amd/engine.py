@@ -134,6 +134,7 @@ class DiTEngine:
         self.group_dycond = True    # ONE launch for the caption-token gradients of all cross-attention kv projections of a group (A/B: False)
         self.group_adaln = True     # one launch for the condition-vector gradients of all adaLN layers of a group (A/B: False)
         self._posb = None
+        self.moe_cache_dact = True  # the MoE fc1 epilogue stores gelu'(h) instead of h; the fc2 dgrad epilogue multiplies by it (A/B: False)
         self.batch_adaln = True     # the modulation of ALL blocks from one GEMM per forward (A/B: False = one small GEMM per block)
         self._adaln = self._adaln_region()
         self.gemm_tail_mode = int(os.environ.get("MD_GEMM_TAIL", "0"))   # md_gemm_args.tail_mode: 0 = the library decides, 1 = never, 2 = always (A/B)
@@ -582,12 +583,13 @@ class DiTEngine:
                 self._override_routing(t, self.route_override[n], B, S, E, k)
             t.xin = self.empty(E, Bk, d)
             hip.check(L.md_gather_rows(t.xm3.data_ptr(), d, t.rowidx.data_ptr(), t.xin.data_ptr(), d, E * Bk, d, st), "gather")
-            t.hpre = self.empty(E, Bk, f)
-            t.hact = self.empty(E, Bk, f)
+            t.hpre = self.empty(E, Bk, f)         # the pre-activation -- or, with moe_cache_dact, gelu'(pre-activation): nothing but
+            t.hact = self.empty(E, Bk, f)         # the backward's activation derivative ever reads it (md_gemm_args.dact_cached)
+            t.hpre_is_dact = 1 if self.moe_cache_dact else 0
             w1, w2 = self.S[n + ".mlp.w1"], self.S[n + ".mlp.w2"]       # [E, d, f], [E, f, d]
             self._gemm(A=t.xin.data_ptr(), B=w1.data_ptr(), C=t.hact.data_ptr(), C2=t.hpre.data_ptr(), M=Bk, N=f, K=d, lda=d,
                        ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f, sC2=Bk * f, batch=E, ksplit=1, a_kcontig=1,
-                       b_kcontig=0, mode=hip.EPI_STORE_BF16, act=hip.ACT_GELU_ERF, alpha=1.0)
+                       b_kcontig=0, mode=hip.EPI_STORE_BF16, act=hip.ACT_GELU_ERF, alpha=1.0, dact_cached=t.hpre_is_dact)
             t.h2 = self.empty(E, Bk, d)
             self._gemm(A=t.hact.data_ptr(), B=w2.data_ptr(), C=t.h2.data_ptr(), M=Bk, N=d, K=f, lda=f, ldb=d, ldc=d,
                        sA=Bk * f, sB=f * d, sC=Bk * d, batch=E, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_STORE_BF16,
@@ -656,7 +658,7 @@ class DiTEngine:
             dhpre = self.empty(E, Bk, f)
             self._gemm(A=dh2.data_ptr(), B=w2.data_ptr(), C=dhpre.data_ptr(), aux=t.hpre.data_ptr(), M=Bk, N=f, K=d, lda=d,
                        ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d, sC=Bk * f, sAux=Bk * f, batch=E, ksplit=1, a_kcontig=1,
-                       b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, alpha=1.0)
+                       b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, alpha=1.0, dact_cached=t.hpre_is_dact)
             # dW1[e][d, f] += xin[e]^T dhpre[e]
             self.gemm_f32_acc(out_ptr=g1.data_ptr(), M=d, N=f, K=Bk, ldo=f, batch=E, sOut=d * f, A=t.xin.data_ptr(),
                               B=dhpre.data_ptr(), lda=d, ldb=f, sA=Bk * d, sB=Bk * f, a_kcontig=0, b_kcontig=0)

@@ -117,6 +117,7 @@ class GemmArgs(Structure):
         ("timeline", c_void_p), ("chosen_variant", c_void_p), ("A_list", c_void_p), ("B_list", c_void_p), ("list_segments", c_int32),
         ("problems", c_void_p), ("n_problems", c_int32), ("cu_limit", c_int32),
         ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64), ("tail_mode", c_int32), ("tail_used", c_void_p),
+        ("dact_cached", c_int32),
     ]
 
 
@@ -273,7 +274,7 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
          act=ACT_NONE, alpha=1.0, bias=None, res=None, ldr=0, gate=None, ldg=0, rows_per_sample=0,
          aux=None, ldaux=0, C2=None, ldc2=0, batch=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sAux=0, sSplit=0, ksplit=1,
          variant=GEMM_AUTO, raster_group_n=0, timeline=None, stream=None, expect=0, A_list=None, B_list=None, list_segments=0, chosen=None, cu_limit=0,
-         tail_ws=None, tail_mode=0, tail_used=None):
+         tail_ws=None, tail_mode=0, tail_used=None, dact_cached=0):
     """Raw-pointer GEMM launch.  A/B/C/... are ints (device addresses) or torch tensors.  tail_ws: a torch tensor used as the
     workspace of the whole-rounds + split-K-tail form (md_gemm_args.tail_ws); tail_used: list that receives the split it ran with (0 = not used)."""
     def ptr(x):
@@ -284,7 +285,7 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, a_kcontig=True, b_kcontig=True, mod
                  M, N, K, lda, ldb, ldc, ldc2, ldr, ldg, ldaux, sA, sB, sC, sC2, sBias, sAux, sSplit,
                  rows_per_sample, batch, ksplit, int(a_kcontig), int(b_kcontig), mode, act, alpha, variant, raster_group_n,
                  ptr(timeline), None, ptr(A_list), ptr(B_list), list_segments, None, 0, cu_limit,
-                 ptr(tail_ws), (tail_ws.numel() * tail_ws.element_size()) if tail_ws is not None else 0, tail_mode, None)
+                 ptr(tail_ws), (tail_ws.numel() * tail_ws.element_size()) if tail_ws is not None else 0, tail_mode, None, dact_cached)
     ch, tu = ctypes.c_int32(-1), ctypes.c_int32(-1)
     a.chosen_variant = ctypes.addressof(ch)
     a.tail_used = ctypes.addressof(tu)

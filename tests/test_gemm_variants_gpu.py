@@ -126,6 +126,20 @@ def test_moe_grouped(hip, variant, Bk, d, f):
     assert _run(hip, variant, A=dHp, B=W1, C=dX, M=Bk, N=d, K=f, lda=f, ldb=f, ldc=d, sA=Bk * f, sB=d * f, sC=Bk * d, batch=E,
                 a_kcontig=1, b_kcontig=1)
     _close(dX, torch.einsum("erf,edf->erd", dHp.float(), W1.float()), what="fc1 dgrad")
+    # md_gemm_args.dact_cached: the forward stores gelu'(pre-activation) in C2, the backward epilogue multiplies by it
+    Hd = torch.full_like(H, float("nan"))
+    H2 = torch.full_like(H, float("nan"))
+    assert _run(hip, variant, A=X, B=W1, C=H2, C2=Hd, M=Bk, N=f, K=d, lda=d, ldb=f, ldc=f, ldc2=f, sA=Bk * d, sB=d * f, sC=Bk * f,
+                sC2=Bk * f, batch=E, a_kcontig=1, b_kcontig=0, act=hip.ACT_GELU_ERF, dact_cached=1)
+    _close(H2, torch.nn.functional.gelu(raw), what="fc1 gelu (derivative cached)")
+    xr = raw.to(torch.bfloat16).float().requires_grad_(True)
+    torch.nn.functional.gelu(xr).sum().backward()
+    _close(Hd, xr.grad, what="cached gelu'")
+    dHc = torch.full_like(H, float("nan"))
+    assert _run(hip, variant, A=dO, B=W2, C=dHc, aux=Hd, M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d,
+                sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, dact_cached=1)
+    _close(dHc, torch.einsum("erd,efd->erf", dO.float(), W2.float()) * Hd.float(), what="dact from the cached derivative")
+    _close(dHc, dHp.float(), rel=2e-2, what="cached vs recomputed derivative")
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -425,6 +425,29 @@ def test_batched_adaln_equals_per_block(hip):
         assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-12, k
 
 
+def test_moe_cached_activation_derivative_equals_recomputed(hip):
+    """md_gemm_args.dact_cached (the expert-choice MoE, /root/reference/micro_diffusion/models/dit.py:124,131-142): the fc1 epilogue stores
+    gelu'(h) instead of h and the fc2 dgrad epilogue multiplies by it, against recomputing gelu' from the stored h: same loss
+    (the forward is unchanged), gradients equal up to the bf16 rounding of the stored derivative."""
+    cfg = orc.tiny_config()
+    sd = orc.dezero_state_dict(orc.synth_state_dict(cfg, 51))
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, 4, 52)
+    gb = {k: t.cuda() for k, t in batch.items()}
+    noise = (rnd.cuda(), epsn.cuda(), mnoise.cuda())
+    out = {}
+    for cached in (True, False):
+        m = _product(cfg, sd)
+        m.dit.engine.moe_cache_dact = cached
+        m._noise_fn = lambda b: noise
+        loss = m.train_microbatch(gb)
+        torch.cuda.synchronize()
+        out[cached] = (float(loss), {k: p.grad.clone() for k, p in m.dit.named_parameters()})
+    assert out[True][0] == out[False][0]
+    for k in out[True][1]:
+        a, b = out[True][1][k].double(), out[False][1][k].double()
+        assert float((a - b).norm()) <= 1e-2 * float(b.norm()) + 1e-12, k
+
+
 def test_ema_weights_are_the_ones_evaluated(hip):
     """train.evaluate swaps the EMA weights in: with smoothing 0 the EMA equals the current weights and the eval loss
     is unchanged; with a frozen EMA (smoothing 1 after the first EMA batch) the eval loss is the loss of the OLD weights."""
