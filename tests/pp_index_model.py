@@ -167,3 +167,49 @@ def quad_rows_model(wr, wc, IH, JH):
     V0, V1 = sel(odd, W[2], nb(W[3], 1)), sel(nodd, W[3], nb(W[2], 1))
     T = [sel(hi2, U0, nb(V0, 2)), sel(hi2, U1, nb(V1, 2)), sel(nhi2, V0, nb(U0, 2)), sel(nhi2, V1, nb(U1, 2))]
     return [[[tag for pair in T[t][lane] for tag in pair] for lane in range(64)] for t in range(4)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Work partition of the persistent kernel with the "whole rounds + split-K tail" form (gemm_pp.hip: kernel prologue, stager_open,
+# md_gemm_pp_plan_tail): which workgroup runs which (item, k-tile range).
+# ----------------------------------------------------------------------------------------------------------------------
+def plan_tail(total, nk, cus, tail_mode=0, ws_units=256):
+    """md_gemm_pp_plan_tail: returns (G, tail_first, units, split, tail_nk); units = 0: no tail (G = min(total, cus))."""
+    G = cus & ~7
+    plain = (min(total, cus), total, 0, 0, 0)
+    if tail_mode == 1 or G < 8 or total <= G:
+        return plain
+    r = total % G
+    if r == 0 or r * 2 > G:
+        return plain
+    iters = nk // 2
+    tile_us = 3.1 * iters
+    s, best = 0, (-1e30 if tail_mode == 2 else 2.0)
+    for c in range(iters, 1, -1):
+        if iters % c or r * c > G or r * c > ws_units:
+            continue
+        if tail_mode == 2:
+            s = c
+            break
+        gain = tile_us * (1.0 - 1.0 / c) - (0.13 * r * c + 6.0)
+        if gain > best:
+            best, s = gain, c
+    if s < 2:
+        return plain
+    return (G, total - r, r * s, s, nk // s)
+
+
+def workgroup_items(b, G, total, nk, tail_first, units, split, tail_nk):
+    """What workgroup b of a grid of G walks: [(item, first k-tile, k-tiles)], in its stream order (kernel prologue + stager_open)."""
+    x, j = b & 7, b >> 3
+    body = tail_first if units else total
+    q, r = body >> 3, body & 7
+    lo = x * (q + 1) if x < r else r * (q + 1) + (x - r) * q
+    cnt = q + (1 if x < r else 0)
+    stride = (G - x + 7) >> 3
+    count = (cnt - j + stride - 1) // stride if j < cnt else 0
+    out = [(lo + j + n * stride, 0, nk) for n in range(count)]
+    if b < units:
+        t = b // split
+        out.append((tail_first + t, (b - t * split) * tail_nk, tail_nk))
+    return out

@@ -78,6 +78,16 @@ def _rank_main(rank, world, port, exchange, out_path, dp_mode="allreduce"):
             assert tr.stale_foreign_chunks
             tr.consolidate()
             shadow_ok = shadow_ok and torch.equal(flat["s"], flat["p"].to(torch.bfloat16)) and float(flat["g"].abs().max()) == 0.0
+        # the exact replica checksum (md_checksum_u16 over the bf16 shadow per bucket, int64 MIN / MAX all-reduces): identical replicas
+        # pass; ONE bf16 ulp in one weight of one rank must be seen (the fp32 sum of squares it replaces resolved ~4e-3)
+        in_sync = tr.replicas_in_sync()
+        if rank == 1:
+            w = flat["s"].view(torch.int16)
+            w[12345] += 1                                  # one ulp of one bf16 weight
+        flipped_seen = not tr.replicas_in_sync()
+        if rank == 1:
+            flat["s"].view(torch.int16)[12345] -= 1
+        shadow_ok = shadow_ok and in_sync and flipped_seen and tr.replicas_in_sync()
         # every rank must hold identical weights after the step (no broadcast ever happens)
         mine = flat["p"].detach().cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]

@@ -197,6 +197,40 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
         assert r < 2e-2, f"{name} rel-rms {r}"
 
 
+def test_checksum_u16_is_exact(hip):
+    """md_checksum_u16 (the replica-consistency check of the data-parallel step): both sums against exact integer arithmetic in
+    numpy, bit-identical across repeated launches, and sensitive to one flipped bit, a sign flip and a swap of two elements."""
+    import numpy as np
+    torch.manual_seed(3)
+    n = 8 * 100003
+    x = torch.randn(n, device=DEV).to(torch.bfloat16)
+    L, st = hip.lib(), hip.stream_ptr()
+
+    def cs(t):
+        out = torch.zeros(2, device=DEV, dtype=torch.int64)
+        hip.check(L.md_checksum_u16(t.data_ptr(), t.numel(), out.data_ptr(), st), "md_checksum_u16")
+        torch.cuda.synchronize()
+        return out.cpu().numpy().astype(np.uint64)
+
+    w = x.view(torch.int16).cpu().numpy().astype(np.uint16).astype(np.uint64)
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = ((idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)) | np.uint64(1)
+        want = np.array([w.sum(dtype=np.uint64), (w * h).sum(dtype=np.uint64)], dtype=np.uint64)
+    got = cs(x)
+    assert (got == want).all(), (got, want)
+    assert (cs(x) == got).all()
+    y = x.clone()
+    y.view(torch.int16)[777] ^= 1
+    assert (cs(y) != got).any()
+    y = x.clone()
+    y[5] = -y[5]
+    assert (cs(y) != got).any()
+    y = x.clone()
+    y[[10, 20]] = y[[20, 10]]
+    assert cs(y)[0] == got[0] and cs(y)[1] != got[1], "a permutation keeps the plain sum and must change the index-weighted one"
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 @pytest.mark.parametrize("M,f", [(300, 512), (77 * 3 + 1, 2816), (1031, 776), (65536, 1792), (19, 8)])
 def test_swiglu_shapes(hip, M, f):

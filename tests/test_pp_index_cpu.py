@@ -52,3 +52,36 @@ def test_epilogue_row_run_layout():
                             for e in range(8):
                                 seen[row, col + e] += 1
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("tail_mode", [0, 2])
+def test_tail_partition_covers_every_k_tile_once(tail_mode):
+    """Whole rounds + split-K tail (md_gemm_args.tail_ws): for the launch shapes of the 256-image step on the free chip and on the
+    248 CUs an RCCL kernel leaves, and for a sweep of tile counts, the host model of the kernel's work partition visits every
+    (output tile, k-tile) exactly once, a tail unit is always a workgroup's LAST item and whole iterations (two k-tiles) long, and
+    the whole tiles are dealt evenly (whole rounds)."""
+    cases = [(256, 16, 248), (256, 12, 248), (768, 12, 248), (576, 16, 256), (616, 16, 256), (704, 16, 248), (256, 44, 248), (1920, 16, 256),
+             (325, 18, 256), (355, 8, 256)]
+    cases += [(t, nk, cu) for t in range(250, 700, 37) for nk in (4, 12, 16) for cu in (256, 250, 248, 240)]
+    took = 0
+    for total, nk, cus in cases:
+        G, tail_first, units, split, tail_nk = pm.plan_tail(total, nk, cus, tail_mode)
+        seen = np.zeros((total, nk), dtype=np.int32)
+        loads = []
+        for b in range(G):
+            items = pm.workgroup_items(b, G, total, nk, tail_first, units, split, tail_nk)
+            for n, (item, k0, kn) in enumerate(items):
+                assert kn % 2 == 0 and kn >= 2
+                if kn != nk:
+                    assert n == len(items) - 1 and item >= tail_first, "a tail unit is the workgroup's last item"
+                seen[item, k0:k0 + kn] += 1
+            loads.append(sum(kn for _, _, kn in items))
+        assert (seen == 1).all(), (total, nk, cus, G, tail_first, units, split)
+        if units:
+            took += 1
+            assert tail_first % G == 0 and units <= G and split >= 2 and split * tail_nk == nk
+            assert max(loads) - min(loads) <= tail_nk, "whole rounds + at most one unit per workgroup"
+    assert took >= 5
+    # the north_star's per-rank shape under the CU hold: 256 tiles on 248 workgroups, K = 1024
+    assert pm.plan_tail(256, 16, 248, 0)[2:4] == (32, 4)
+    assert pm.plan_tail(576, 16, 256, 0)[2] == 0, "64 left-over tiles: the raw-tile traffic would cost more than the round it saves"
