@@ -14,7 +14,7 @@ Extra keys of the line (the headline fields are unchanged by them):
   value_mb256_cu248, n8_ceiling   the same with every persistent-GEMM grid limited to the 248 CUs an 8-channel RCCL kernel leaves
                  (the rank-of-8 step emulated on one GPU) and 8 x that / the headline; `_whole_tiles` = without the split-K tail;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
-                 the committed rocprofv3 PMC passes (profiles/r4_gemm_traffic.json: counters need rocprofv3 around the process,
+                 the committed rocprofv3 PMC passes (profiles/r5_gemm_traffic.json: counters need rocprofv3 around the process,
                  so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
                  the library it was measured on and `traffic` is null when that differs from the running build);
   roofline_hbm   the bandwidth-bound kernel classes (attention, LayerNorm, QK-LayerNorm, SwiGLU, gate backward, split-K reduce):
@@ -197,7 +197,7 @@ class Stage:
         torch.cuda.empty_cache()
 
 
-TRAFFIC_FILE = "r4_gemm_traffic.json"
+TRAFFIC_FILE = "r5_gemm_traffic.json"
 
 
 def gemm_traffic():
