@@ -125,6 +125,25 @@ def test_tail_moe_grouped(hip, tws):
     _close(dHp, torch.einsum("erd,efd->erf", dO.float(), W2.float()) * xp.grad, what="dact")
 
 
+def test_tail_with_bias_and_ragged_rows(hip, tws):
+    """The batched adaLN GEMM (all blocks' modulation Linear as one launch: dit.py:222-225 has bias=True) is the production user of the
+    tail WITH a bias and with fewer rows than a tile: [B, 1024] x [N_all, 1024]^T, here 300 rows x 34,048 columns = 2 x 133 tiles
+    = one round of 256 + 10."""
+    torch.manual_seed(23)
+    M, N, K = 300, 256 * 133, 1024
+    A, As, lda = _operand(M, K, 1)
+    B, Bs, ldb = _operand(N, K, 1, 0.05)
+    bias = torch.randn(N, device=dev)
+    C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    used = _pair(hip, tws, 0, A=As, B=Bs, C=C, bias=bias, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N)
+    assert used >= 2
+    _close(C, A.float() @ B.float().t() + bias, what="tail with bias")
+    auto = []
+    hip.gemm(As, Bs, C, M, N, K, lda=lda, ldb=ldb, ldc=N, bias=bias, tail_ws=tws, tail_mode=0, tail_used=auto)
+    torch.cuda.synchronize()
+    _close(C, A.float() @ B.float().t() + bias, what="library's own choice")
+
+
 def test_tail_refused_where_it_does_not_apply(hip, tws):
     """Whole rounds (nothing left over), a left-over larger than half a round, fp32 slices: the plain form runs, tail_used = 0."""
     A = torch.randn(65536, 256, device=dev).to(torch.bfloat16)
