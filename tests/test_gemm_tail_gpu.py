@@ -222,4 +222,4 @@ def test_cu_limit_on_the_rank_of_8_shape(hip, tws):
         json.dump(out, fh, indent=1)
     assert used[0] >= 2, "the library's own rule must take the tail on this shape"
     assert t_tail <= 1.02 * t_lim, out            # never slower than two rounds of whole tiles
-    assert t_tail <= 1.45 * t_free, out           # measured 1.3-1.4x (whole tiles: 1.5x; the launch's start-up / drain is 10 us of its 35)
+    assert t_tail <= 1.5 * t_free, out            # measured 1.41-1.42x on three boxes (whole tiles: 1.52-1.53x; the launch's start-up / drain is 10 us of its 36)
