@@ -226,15 +226,17 @@ def adaln_order(name: str):
 def bucket_key(name: str, ndim: int = 2) -> str:
     """Data-parallel bucket a parameter belongs to: one per DiT block ("blocks.17", "patch_mixer.3"), "final_layer", "rest"
     (embedders, caption block, mixer maps) -- the segments whose backward finishes together (engine.backward's on_segment
-    hand-off) --, "adaln" (the modulation weights of ALL blocks, first in the flat buffers: complete with the last segment of the
-    backward, needed by the first GEMM after the condition vector in the forward) and "small" for every one-dimensional tensor (biases, LayerNorm weights): those live in one region at the end of
+    hand-off) --, "adaln.m" / "adaln.b" (the modulation weights of all mixer / all backbone blocks, contiguous at the head of the flat
+    buffers and needed together by the first GEMM after the condition vector in the forward; "adaln.b" is complete, and exchanged,
+    when the backward of the FIRST backbone block is done -- the mixer's backward still covers it --, "adaln.m" with the last
+    segment) and "small" for every one-dimensional tensor (biases, LayerNorm weights): those live in one region at the end of
     the flat buffers, are exchanged as one all-reduce and updated by every rank (the engine reads them from the fp32 masters,
     so every replica must hold them exactly; the sharded optimiser step only owns slices of the matrix-shaped buckets)."""
     if ndim <= 1:
         return "small"
     top = name.split(".")
     if is_block_adaln(name):
-        return "adaln"
+        return "adaln.m" if top[0] == "patch_mixer" else "adaln.b"
     if top[0] in ("blocks", "patch_mixer") and len(top) > 1 and top[1].isdigit():
         return ".".join(top[:2])
     return "final_layer" if top[0] == "final_layer" else "rest"

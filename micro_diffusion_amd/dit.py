@@ -28,7 +28,7 @@ _BUCKET_ALIGN = 1024  # elements; every data-parallel bucket starts (and therefo
 def flat_layout(table):
     """Offsets (in elements) of every parameter inside the flat buffers: matrix-shaped tensors in table order (= the reference's
     registration order, so the tensors of a block are contiguous and [w1; w2] of a SwiGLU stay adjacent; the modulation weights of
-    all blocks first, as one contiguous "adaln" bucket), each padded to _ALIGN, a new data-parallel bucket (arch.bucket_key)
+    all blocks first, contiguous, as the two buckets "adaln.m" / "adaln.b"), each padded to _ALIGN, a new data-parallel bucket (arch.bucket_key)
     starting on a multiple of _BUCKET_ALIGN; then all one-dimensional tensors (the "small" bucket, the block adaLN biases first)
     in one region at the end."""
     offs, total, prev = {}, 0, None

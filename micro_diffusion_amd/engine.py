@@ -967,7 +967,8 @@ class DiTEngine:
             ym = y2
         tp.ym = ym
         # ---- the modulation vectors of every block (mixer + backbone) from one GEMM on gelu(c), dit.py:222-225
-        seg("adaln")
+        seg("adaln.m")
+        seg("adaln.b")
         mod_all = self._adaln_all(gc, B) if (self.batch_adaln and self._adaln is not None) else None
         tp.mixer = []
         for bp in self.mixer:

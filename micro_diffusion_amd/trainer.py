@@ -396,6 +396,7 @@ class GradSync:
         for key, lo, hi in self.bucket_list:
             self.ranges.setdefault(key, []).append((lo, hi))
         self.pending = []
+        self._adaln_b_sent = False           # the backbone's adaLN bucket went out with "blocks.0" in this backward
         self._wire = collections.deque()     # every collective handle in issue order, for in_flight()
         self.active = False
         self.buckets = 0                 # buckets handed over in the current step (= partial-sum slots in use)
@@ -545,10 +546,18 @@ class GradSync:
             return
         for lo, hi in self.ranges.get(name, []):
             self._exchange(lo, hi)
-        if name == "rest":                # the last segment of a backward: the blocks' modulation weights ("adaln": every block's
-            for key in ("adaln", "small"):    # backward wrote its part) and the one-dimensional tensors are complete too
+        # The modulation weights of all blocks live in two buckets of their own (arch.bucket_key): the backbone's part is complete
+        # once the backward of the FIRST backbone block is enqueued (409 MB of the 2.33 GB at XL/2: handed over here, the mixer's
+        # backward still covers it), the mixer's part (57 MB) and the one-dimensional tensors with the last segment.
+        if name == "blocks.0" and not self._adaln_b_sent:
+            self._adaln_b_sent = True
+            for lo, hi in self.ranges.get("adaln.b", []):
+                self._exchange(lo, hi)
+        if name == "rest":
+            for key in (() if self._adaln_b_sent else ("adaln.b",)) + ("adaln.m", "small"):
                 for lo, hi in self.ranges.get(key, []):
                     self._exchange(lo, hi)
+            self._adaln_b_sent = False
 
     def finish(self) -> int:
         """Wait for every bucket; returns the number of norm partial-sum slots filled (0 = the optimiser takes the norm itself;

@@ -226,7 +226,7 @@ def test_shard_plan_partitions_every_bucket():
     # the engine's batched adaLN GEMM (DiTEngine._adaln_region) reads them as one operand
     from micro_diffusion_amd.arch import plan_blocks
     mixer, backbone = plan_blocks(m.config)
-    assert buckets[0][0] == "adaln" and buckets[0][1] == 0
+    assert [b[0] for b in buckets[:2]] == ["adaln.m", "adaln.b"] and buckets[0][1] == 0 and buckets[0][2] == buckets[1][1]
     shapes = {s.name: s.shape for s in m._table}
     for suffix, first in ((".adaLN_modulation.1.weight", 0), (".adaLN_modulation.1.bias", buckets[-1][1])):
         nxt = first
@@ -234,7 +234,8 @@ def test_shard_plan_partitions_every_bucket():
             nm = bp.name + suffix
             assert offs[nm] == nxt, (nm, offs[nm], nxt)
             nxt += int(np.prod(shapes[nm]))
-    assert buckets[0][2] >= sum(int(np.prod(shapes[bp.name + ".adaLN_modulation.1.weight"])) for bp in list(mixer) + list(backbone))
+    assert buckets[1][2] >= sum(int(np.prod(shapes[bp.name + ".adaLN_modulation.1.weight"])) for bp in list(mixer) + list(backbone))
+    assert buckets[0][2] == sum(int(np.prod(shapes[bp.name + ".adaLN_modulation.1.weight"])) for bp in mixer), "no gap between the two parts"
     w1 = next(s for s in m._table if s.name == "blocks.4.mlp.w1.weight")
     assert offs["blocks.4.mlp.w2.weight"] == offs["blocks.4.mlp.w1.weight"] + int(np.prod(w1.shape))
     for world in (1, 2, 4, 8, 16):
