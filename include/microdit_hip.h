@@ -134,7 +134,9 @@ enum md_gemm_variant {
     MD_GEMM_REG128 = 1,   /* 128 x 128 tile, register-staged global -> LDS, 3 workgroups / CU                        */
     MD_GEMM_DMA128 = 2,   /* 128 x 128 tile, LDS-DMA double buffer                                                   */
     MD_GEMM_PACED256 = 3, /* 256 x 256 tile, LDS-DMA double buffer, DMA issue paced over the k-steps                 */
-    MD_GEMM_PP256 = 4     /* 256 x 256 tile, persistent, two wave groups half a phase apart, 8-slot half-tile ring   */
+    MD_GEMM_PP256 = 4,    /* 256 x 256 tile, persistent, two wave groups half a phase apart, 8-slot half-tile ring   */
+    MD_GEMM_W4 = 5        /* 256 x 256 tile, persistent, 4 waves x 128 x 128 (accumulators in the AGPR half of the file),
+                             register-staged operands; K-contiguous x K-contiguous (nn.Linear forward) only          */
 };
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);

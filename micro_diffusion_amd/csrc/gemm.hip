@@ -627,8 +627,9 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     const int64_t tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256) * (int64_t)a->batch * a->ksplit;
     const int64_t kspan = (a->K + a->ksplit - 1) / a->ksplit;   // contraction length one workgroup walks
     int variant = a->variant;
-    if (variant < MD_GEMM_AUTO || variant > MD_GEMM_PP256) return MD_BAD_ARG;
-    if (variant >= MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_NOT_ELIGIBLE;
+    if (variant < MD_GEMM_AUTO || variant > MD_GEMM_W4) return MD_BAD_ARG;
+    if (variant == MD_GEMM_PP256 && !md_gemm_pp_eligible(a)) return MD_NOT_ELIGIBLE;
+    if (variant == MD_GEMM_W4 && !md_gemm_w4_eligible(a)) return MD_NOT_ELIGIBLE;
     if ((a->A_list || a->B_list) && !(a->A_list && a->B_list && md_gemm_pp_eligible(a))) return MD_BAD_ARG;   // operand lists: PP256 only
     if (a->A_list) variant = MD_GEMM_PP256;
     if (variant == MD_GEMM_AUTO) {
@@ -655,6 +656,7 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
         a_copy.raster_group_n = (int)g;
     }
     if (a->chosen_variant) *a->chosen_variant = variant;
+    if (variant == MD_GEMM_W4) return md_gemm_w4_launch(a, stream);
     if (variant >= MD_GEMM_PP256) return md_gemm_pp_launch(a, stream);
     const int64_t tiles = ((a->M + TMv - 1) / TMv) * ((a->N + TMv - 1) / TMv);
     dim3 grid((unsigned)tiles, (unsigned)(a->batch * a->ksplit), 1);

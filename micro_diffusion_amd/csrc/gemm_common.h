@@ -24,3 +24,7 @@ __device__ __forceinline__ float apply_dact(float v, int act) {
 // gemm_pp.hip
 bool md_gemm_pp_eligible(const md_gemm_args* a);
 int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream);
+
+// gemm_w4.hip
+bool md_gemm_w4_eligible(const md_gemm_args* a);
+int md_gemm_w4_launch(const md_gemm_args* a, hipStream_t stream);

@@ -238,14 +238,16 @@ def _xl2_curve_slice(name, t):
 XL2_CURVE_FIRST_BATCH = 100     # the 8 steps are batches 100 .. 107 of the YAML's schedule (lr 9.6e-6 .. 1.03e-5)
 
 
-def gen_curve_xl2(steps=8, B=4):
-    """`steps` optimiser steps of the UNMODIFIED reference at MicroDiT_XL_2 widths (dit.py:671-709; model.py:181-210
+def gen_curve_xl2(steps=8, B=4, fname="xl2_curve.npz", threads=None):
+    """VERDICT r4 #7 (8 steps, `xl2_curve.npz`) and r5 #6 (250 steps, `xl2_curve_250.npz`: same recipe, batches 100 .. 349): `steps` optimiser steps of the UNMODIFIED reference at MicroDiT_XL_2 widths (dit.py:671-709; model.py:181-210
     produces the loss series) -- torch AdamW (lr 2.4e-4, wd 0.1), clip_grad_norm_(0.25), the YAML's cosine schedule with its
     2500-batch linear warm-up (configs/res_256_pretrain.yaml:52-61) entered at batch 100 (a non-zero learning rate; ramping to
     the full 2.4e-4 within 8 steps instead makes the de-zeroed network diverge -- loss 1.3 -> 4.6 -- in the reference itself),
     seed-18 initialisation with the all-zero tensors de-zeroed (the network matters from step 0), batch 4, recorded noise
     (oracle.curve_inputs).  Records per-step loss, pre-clip gradient norm and initial / final values of slices of six named
     tensors."""
+    if threads:
+        torch.set_num_threads(threads)
     cfg = orc.xl2_config()
     torch.manual_seed(18)
     dit = ref_dit_from_cfg(cfg)
@@ -277,9 +279,9 @@ def gen_curve_xl2(steps=8, B=4):
         print(step, loss.item(), gn.item(), f"{time.time() - t0:.1f}s", flush=True)
     for k in XL2_CURVE_TENSORS:
         out["final/" + k] = _xl2_curve_slice(k, named[k]).numpy()
-    np.savez_compressed(os.path.join(OUT, "xl2_curve.npz"), loss=np.array(losses), gnorm=np.array(gnorms), steps=np.int64(steps),
+    np.savez_compressed(os.path.join(OUT, fname), loss=np.array(losses), gnorm=np.array(gnorms), steps=np.int64(steps),
                         batch=np.int64(B), first_batch=np.int64(XL2_CURVE_FIRST_BATCH), **out)
-    print("xl2_curve.npz")
+    print(fname)
 
 
 def gen_sampler():
@@ -362,6 +364,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "xl2_curve":
         gen_curve_xl2()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2_curve_250":
+        # 250 optimiser steps of the unmodified reference at XL/2 widths (~25 min on 6-8 host threads)
+        gen_curve_xl2(steps=250, fname="xl2_curve_250.npz", threads=int(os.environ.get("GEN_THREADS", "8")))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "curve_hot":
         gen_curve_hot()

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["reg128", "dma128", "paced256", "pp256"]
+VARIANTS = ["reg128", "dma128", "paced256", "pp256", "w4"]
 dev = "cuda"
 
 
@@ -116,8 +116,8 @@ def test_moe_grouped(hip, variant, Bk, d, f):
     dHp = torch.empty_like(H)
     ok = _run(hip, variant, A=dO, B=W2, C=dHp, aux=Hp, M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d,
               sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF)
-    if not ok:      # pp256 builds its operand-carrying epilogues (residual, activation derivative) for interior tiles only
-        assert variant == "pp256" and (Bk % 256 or f % 256)
+    if not ok:      # pp256 / w4 build their operand-carrying epilogues (residual, activation derivative) for interior tiles only
+        assert variant in ("pp256", "w4") and (Bk % 256 or f % 256)
         pytest.skip("pp256 refuses the ragged activation-derivative launch (the library's own choice falls back to the 2-stage kernels)")
     xp = Hp.float().requires_grad_(True)
     torch.nn.functional.gelu(xp).sum().backward()
@@ -177,8 +177,7 @@ def test_pp256_refuses_what_it_cannot_run(hip):
     assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, variant=99, expect=None) == -1
 
 
-@pytest.mark.parametrize("variant", ["pp256"])
-@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("variant,akc,bkc", [("pp256", 1, 1), ("pp256", 1, 0), ("pp256", 0, 0), ("w4", 1, 1)])
 def test_pp256_race_screen(hip, akc, bkc, variant):
     """The ping-pong kernel orders its LDS ring with counted waits and barriers only: repeat a many-tile launch (several tiles
     per workgroup, short K so tile hand-overs dominate) and require bit-identical results, on an idle chip and while
@@ -201,9 +200,9 @@ def test_pp256_race_screen(hip, akc, bkc, variant):
                  mode=hip.EPI_STORE_F32 if f32 else hip.EPI_STORE_BF16, variant=hip.GEMM_VARIANT_NAMES[variant])
         torch.cuda.synchronize()
         outs.append(C)
-    _close(outs[0], A.float() @ B.float().t(), rel=2e-3 if f32 else 2e-2, what="pp256")
+    _close(outs[0], A.float() @ B.float().t(), rel=2e-3 if f32 else 2e-2, what=variant)
     for o in outs[1:]:
-        assert torch.equal(o, outs[0]), "pp256 result differs between identical launches (LDS ring race)"
+        assert torch.equal(o, outs[0]), f"{variant} result differs between identical launches (LDS ring race)"
 
 
 def _time_us(fn, reps=8):
