@@ -20,6 +20,7 @@
 // (micro_diffusion/models/dit.py:84-89,131-142,224; utils.py:58-61,109-111,172-173,225-233).
 #include "md_common.h"
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -633,7 +634,12 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if ((a->A_list || a->B_list) && !(a->A_list && a->B_list && md_gemm_pp_eligible(a))) return MD_BAD_ARG;   // operand lists: PP256 only
     if (a->A_list) variant = MD_GEMM_PP256;
     if (variant == MD_GEMM_AUTO) {
-        if (md_gemm_pp_eligible(a) && tiles256 >= 192)
+        // W4 (round 6): the 4-wave 16x16x32 kernel where it measured ahead of PP256 -- K-contiguous x K-contiguous launches with
+        // more than one tile per workgroup and no CU hold (profiles/r6_w4_vs_pp256.txt); the md_gemm_args.cu_limit launches of the
+        // data-parallel step keep PP256 and its split-K tail
+        if (md_gemm_w4_eligible(a) && tiles256 > 256 && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4"))
+            variant = MD_GEMM_W4;
+        else if (md_gemm_pp_eligible(a) && tiles256 >= 192)
             variant = MD_GEMM_PP256;
         else if (!a->a_kcontig && !a->b_kcontig && kspan >= 2048 && tiles256 >= 128)
             variant = MD_GEMM_PACED256;   // weight gradients (TN) when the caller's split-K makes ~one full round of 256 workgroups

@@ -3,7 +3,7 @@ timed back to back on one model, twice, in alternating order).
 
     python scripts/ab_step.py [--microbatch 256] [--steps 3] name:key=value,key=value ...
 e.g. python scripts/ab_step.py --microbatch 256 r2:ksplit_min_items=128,group_adaln=0,use_arena=0 new:ksplit_min_items=192
-Keys are DiTEngine attributes (ints / bools)."""
+Keys are DiTEngine attributes (ints / bools), or env.NAME for a library switch read with getenv (MD_GEMM_NO_*)."""
 import argparse
 import json
 import os
@@ -35,7 +35,12 @@ def main():
             kv = dict(o.split("=") for o in opts.split(",") if o)
             for k in base:
                 setattr(eng, k, base[k])
+            for k in [k for k in os.environ if k.startswith("MD_GEMM_NO_")]:
+                del os.environ[k]
             for k, val in kv.items():
+                if k.startswith("env."):                # library switches read with getenv at every launch (e.g. env.MD_GEMM_NO_W4=1)
+                    os.environ[k[4:]] = val
+                    continue
                 base.setdefault(k, getattr(eng, k))
                 setattr(eng, k, type(getattr(eng, k))(int(val)))
             for ar in (eng._tape_arena, eng._scratch_arena):     # the launch sequence may change with the options: re-measure

@@ -10,15 +10,16 @@ from micro_diffusion_amd import hip  # noqa: E402
 
 shapes = [(8192, 8192, 8192), (4096, 4096, 4096), (65536, 1024, 1024), (65536, 3072, 1024), (262144, 768, 768), (16384, 1024, 1024)]
 variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["w4", "pp256"]
+bkc = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 0: B K-strided ([K, N] row-major: dgrads, expert weights)
 dev = "cuda"
 out = []
 for M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-    B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    B = (torch.randn((N, K) if bkc else (K, N), device=dev) * 0.05).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     row = []
     for v in variants:
-        kw = dict(lda=K, ldb=K, ldc=N, variant=hip.GEMM_VARIANT_NAMES[v])
+        kw = dict(lda=K, ldb=K if bkc else N, ldc=N, b_kcontig=bkc, variant=hip.GEMM_VARIANT_NAMES[v])
         hip.gemm(A, B, C, M, N, K, **kw)
         torch.cuda.synchronize()
         best = 1e30
@@ -32,4 +33,4 @@ for M, N, K in shapes:
             best = min(best, e0.elapsed_time(e1) / 8)
         row.append(f"{v} {2.0 * M * N * K / best / 1e9:6.0f}")
     out.append(f"{M}x{N}x{K}: " + "  ".join(row))
-print(os.environ.get("MICRODIT_LIB", "library"), "|", " | ".join(out))
+print(os.environ.get("MICRODIT_LIB", "library"), "NT" if bkc else "NN", "|", " | ".join(out))

@@ -177,7 +177,7 @@ def test_pp256_refuses_what_it_cannot_run(hip):
     assert hip.gemm(A, B, C, 256, 256, 128, lda=192, ldb=192, ldc=256, variant=99, expect=None) == -1
 
 
-@pytest.mark.parametrize("variant,akc,bkc", [("pp256", 1, 1), ("pp256", 1, 0), ("pp256", 0, 0), ("w4", 1, 1)])
+@pytest.mark.parametrize("variant,akc,bkc", [("pp256", 1, 1), ("pp256", 1, 0), ("pp256", 0, 0), ("w4", 1, 1), ("w4", 1, 0)])
 def test_pp256_race_screen(hip, akc, bkc, variant):
     """The ping-pong kernel orders its LDS ring with counted waits and barriers only: repeat a many-tile launch (several tiles
     per workgroup, short K so tile hand-overs dominate) and require bit-identical results, on an idle chip and while
