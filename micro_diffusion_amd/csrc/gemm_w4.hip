@@ -53,6 +53,11 @@ constexpr bool w4_is_dact(int epi) { return epi == PP_E_DACT_GELU || epi == PP_E
 
 
 
+// LDS slab accesses of the epilogue: 8-byte stores and 16-byte loads of the SAME bytes -- through may_alias types, or type-based
+// alias analysis lets hipcc move a row group's loads across the stores of the group that reuses its slab half.
+typedef unsigned w4_u32x2 __attribute__((ext_vector_type(2), may_alias));
+typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4), may_alias));
+
 struct W4Tile {
     int m0, n0, batch;
     int mlim, nlim;            // rows / columns of the tile inside the matrix
@@ -71,33 +76,49 @@ struct W4Tile {
 // bf16(acc) first (= what nn.Linear returns under autocast), then the fused arithmetic on that value, as in gemm_pp.hip.
 // WAIT_LOADS (the first row group): every VM load issued so far -- the k-loop's staging loads, this group's operand loads -- is
 // waited for before the first store is issued; the next k-tile's LDS writes then need no vmcnt (gen_w4_acc.py, FRESH).
-template <int EPI, int I, bool WAIT_LOADS>
-__device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, unsigned char* slab, int wrow, int wcol, int lane_in) {
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));               // lane geometry is recomputed per row group: nothing of it is hoisted out of the tile loop
-    const int r = lane & 15, g = lane >> 4;
-    unsigned char* half = slab + (I & 1) * 4096;
-    // operands of the fused epilogues, in the store-side layout (requested before the accumulators are touched)
-    const int c8 = wcol + r * 8;                                       // first column of this lane's 8 (tile-relative)
-    const bool cok = c8 < et.nlim;
-    uint4 opv[4];
-    uint4 gq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
+// Operands of the fused epilogues for row group I, in the store-side layout (lane = 8 columns of row 4 t + lane / 16).  ONE register
+// set, refreshed in place: as soon as step t of group I has consumed its piece, the same registers request piece t of group I + 1
+// (a whole row group of latency cover without a second set -- hipcc's 92 registers do not hold two).
+struct W4Ops {
+    uint4 v[4];
+    uint4 gq;
+};
+template <int EPI, int I>
+__device__ __forceinline__ void w4_epi_ops(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, int wrow, int wcol, int lane_in, W4Ops& o) {
     if constexpr (EPI == PP_E_RES || w4_is_dact(EPI)) {
+        int lane = lane_in;
+        asm volatile("" : "+v"(lane));
+        const int r = lane & 15, g = lane >> 4;
+        const int c8 = wcol + r * 8;
         const unsigned ldo = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
         const int mlast = et.mlim - 1;
-        const unsigned coff = (unsigned)(cok ? c8 : 0);
+        const unsigned coff = (unsigned)(c8 < et.nlim ? c8 : 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = wrow + 16 * I + 4 * t + g;
-            opv[t] = *reinterpret_cast<const uint4*>(et.opbase + ((unsigned)(row < mlast ? row : mlast) * ldo + coff) * 2u);
+            o.v[t] = *reinterpret_cast<const uint4*>(et.opbase + ((unsigned)(row < mlast ? row : mlast) * ldo + coff) * 2u);
         }
+        o.gq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
         if (EPI == PP_E_RES && et.gbase) {
             int r0 = et.m0 + wrow + 16 * I;                           // wave-uniform: rows_per_sample % 64 == 0 -> one gate row per group
             r0 = r0 < w.M - 1 ? r0 : w.M - 1;
             const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
-            gq = *reinterpret_cast<const uint4*>(et.gbase + ((size_t)(srow * (unsigned)p.ldg) + coff) * 2);
+            o.gq = *reinterpret_cast<const uint4*>(et.gbase + ((size_t)(srow * (unsigned)p.ldg) + coff) * 2);
         }
     }
+}
+
+template <int EPI, int I, bool WAIT_LOADS>
+__device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, unsigned char* slab, int wrow, int wcol, int lane_in,
+                                            W4Ops& ops) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));               // lane geometry is recomputed per row group: nothing of it is hoisted out of the tile loop
+    const int r = lane & 15, g = lane >> 4;
+    unsigned char* half = slab + (I & 1) * 4096;
+    const int c8 = wcol + r * 8;                                       // first column of this lane's 8 (tile-relative)
+    const bool cok = c8 < et.nlim;
+    uint4 (&opv)[4] = ops.v;
+    const uint4 gq = ops.gq;
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
         float a[16];
@@ -105,8 +126,8 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
         else w4_acc_read16<I, 1>(a);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint2 v = make_uint2(cvt_pk_bf16(a[4 * q], a[4 * q + 1]), cvt_pk_bf16(a[4 * q + 2], a[4 * q + 3]));
-            *reinterpret_cast<uint2*>(half + r * 256 + (((32 * (4 * jh + q)) + 8 * g) ^ (r << 4))) = v;
+            const w4_u32x2 v = {cvt_pk_bf16(a[4 * q], a[4 * q + 1]), cvt_pk_bf16(a[4 * q + 2], a[4 * q + 3])};
+            *reinterpret_cast<w4_u32x2*>(half + r * 256 + (((32 * (4 * jh + q)) + 8 * g) ^ (r << 4))) = v;
         }
     }
     if constexpr (WAIT_LOADS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -114,7 +135,8 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int rr = 4 * t + g;
-        const uint4 T = *reinterpret_cast<const uint4*>(half + rr * 256 + ((16 * r) ^ (rr << 4)));
+        const w4_u32x4 Tv = *reinterpret_cast<const w4_u32x4*>(half + rr * 256 + ((16 * r) ^ (rr << 4)));
+        const uint4 T = make_uint4(Tv.x, Tv.y, Tv.z, Tv.w);
         const int row = wrow + 16 * I + rr;
         const bool ok = cok && row < et.mlim;
         uint4 out = T;
@@ -182,11 +204,27 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
 #else
         if (ok) *reinterpret_cast<uint4*>(et.cbase + ((unsigned)row * ldc + (unsigned)c8) * 2u) = out;
 #endif
+        if constexpr ((EPI == PP_E_RES || w4_is_dact(EPI)) && I < 7) {     // this piece is consumed: request the next row group's
+            const unsigned ldo = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
+            const int mlast = et.mlim - 1, nrow = row + 16;
+            opv[t] = *reinterpret_cast<const uint4*>(et.opbase + ((unsigned)(nrow < mlast ? nrow : mlast) * ldo + (unsigned)(cok ? c8 : 0)) * 2u);
+        }
+    }
+    if constexpr (EPI == PP_E_RES && I < 7) {
+        if (et.gbase) {
+            int r0 = et.m0 + wrow + 16 * (I + 1);
+            r0 = r0 < w.M - 1 ? r0 : w.M - 1;
+            const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
+            ops.gq = *reinterpret_cast<const uint4*>(et.gbase + ((size_t)(srow * (unsigned)p.ldg) + (unsigned)(cok ? c8 : 0)) * 2);
+        }
     }
 }
 
+// amdgpu_num_vgpr(92), not 96: when hipcc spills SGPRs (the gated-residual instantiations do) it takes the last allowed VGPR for the
+// spill lanes and was seen to hand out the two registers ABOVE the limit as ordinary temporaries -- v96 / v97, the first staging
+// register.  v[92:95] are the guard band; scripts/check_w4_asm.py (tests/test_build_static.py) audits every build.
 template <int BKC, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(92))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_BREG + 4 * W4_SLAB];   // 160 KiB: the whole LDS of a CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,10 +376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void gemm
 #ifndef W4_X_NOEPI
             unsigned char* const slab = smem + 2 * W4_BREG + wave * W4_SLAB;
             const int wrow = wr * 128, wcol = wc * 128;
-            w4_epi_rows<EPI, 0, true>(p, w, et, slab, wrow, wcol, lane);  w4_epi_rows<EPI, 1, false>(p, w, et, slab, wrow, wcol, lane);
-            w4_epi_rows<EPI, 2, false>(p, w, et, slab, wrow, wcol, lane); w4_epi_rows<EPI, 3, false>(p, w, et, slab, wrow, wcol, lane);
-            w4_epi_rows<EPI, 4, false>(p, w, et, slab, wrow, wcol, lane); w4_epi_rows<EPI, 5, false>(p, w, et, slab, wrow, wcol, lane);
-            w4_epi_rows<EPI, 6, false>(p, w, et, slab, wrow, wcol, lane); w4_epi_rows<EPI, 7, false>(p, w, et, slab, wrow, wcol, lane);
+            W4Ops ops;
+            w4_epi_ops<EPI, 0>(p, w, et, wrow, wcol, lane, ops);
+            w4_epi_rows<EPI, 0, true>(p, w, et, slab, wrow, wcol, lane, ops);  w4_epi_rows<EPI, 1, false>(p, w, et, slab, wrow, wcol, lane, ops);
+            w4_epi_rows<EPI, 2, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 3, false>(p, w, et, slab, wrow, wcol, lane, ops);
+            w4_epi_rows<EPI, 4, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 5, false>(p, w, et, slab, wrow, wcol, lane, ops);
+            w4_epi_rows<EPI, 6, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 7, false>(p, w, et, slab, wrow, wcol, lane, ops);
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
