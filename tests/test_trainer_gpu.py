@@ -154,15 +154,10 @@ def test_loss_curve_hot_1k_steps_vs_reference(hip):
     assert np.median(gper) <= 0.01 and np.percentile(gper, 95) <= 0.05, (np.median(gper), np.percentile(gper, 95))
 
 
-def test_xl2_eight_steps_vs_reference(hip):
-    """VERDICT r4 #7 / north_star "per-step training loss on identical latents ... within tolerance" at the BENCHMARKED widths:
-    8 optimiser steps of MicroDiT_XL_2 (clip 0.25, AdamW, the YAML's warm-up schedule entered at batch 100) on batch 4 with
-    recorded noise, against the series recorded from the UNMODIFIED reference + torch AdamW (oracle/gen_golden.py xl2_curve ->
-    tests/golden/xl2_curve.npz; /root/reference/micro_diffusion/models/model.py:181-210, train.py:29-43,85-86).
-    Asserted: per-step loss within 1 %, pre-clip gradient norm within 5 %, and the 8-step weight UPDATE (final - initial) of
-    slices of six named tensors: cosine >= 0.9 with the reference's update, size within 10 %."""
+def _xl2_series(fixture):
+    """Runs the product on the recipe of oracle/gen_golden.py::gen_curve_xl2 and returns everything the two tests below compare."""
     from micro_diffusion_amd.trainer import FusedAdamW, LRSchedule, Trainer
-    z = np.load(os.path.join(G, "xl2_curve.npz"))
+    z = np.load(os.path.join(G, fixture))
     ref, gref = z["loss"], z["gnorm"]
     steps, B, first = int(z["steps"]), int(z["batch"]), int(z["first_batch"])
     cfg = orc.xl2_config()
@@ -200,6 +195,17 @@ def test_xl2_eight_steps_vs_reference(hip):
         cos = float(d_ref @ d_got / (np.linalg.norm(d_ref) * np.linalg.norm(d_got) + 1e-30))
         upd[k] = {"cosine": cos, "size_ratio": float(np.linalg.norm(d_got) / (np.linalg.norm(d_ref) + 1e-30)),
                   "rel_rms": float(np.linalg.norm(d_got - d_ref) / (np.linalg.norm(d_ref) + 1e-30))}
+    return got, ref, rel, gns, gref, grel, upd
+
+
+def test_xl2_eight_steps_vs_reference(hip):
+    """VERDICT r4 #7 / north_star "per-step training loss on identical latents ... within tolerance" at the BENCHMARKED widths:
+    8 optimiser steps of MicroDiT_XL_2 (clip 0.25, AdamW, the YAML's warm-up schedule entered at batch 100) on batch 4 with
+    recorded noise, against the series recorded from the UNMODIFIED reference + torch AdamW (oracle/gen_golden.py xl2_curve ->
+    tests/golden/xl2_curve.npz; /root/reference/micro_diffusion/models/model.py:181-210, train.py:29-43,85-86).
+    Asserted: per-step loss within 1 %, pre-clip gradient norm within 5 %, and the 8-step weight UPDATE (final - initial) of
+    slices of six named tensors: cosine >= 0.9 with the reference's update, size within 10 %."""
+    got, ref, rel, gns, gref, grel, upd = _xl2_series("xl2_curve.npz")
     import json
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/xl2_curve_8steps.json", "w") as fh:
@@ -211,6 +217,37 @@ def test_xl2_eight_steps_vs_reference(hip):
     assert grel.max() <= 0.05, grel
     for k, u in upd.items():
         assert u["cosine"] >= 0.9 and 0.9 <= u["size_ratio"] <= 1.1, (k, u)
+
+
+def test_xl2_250_steps_vs_reference(hip):
+    """VERDICT r5 #6 / north_star "loss curve matching reference within 1 %": 250 optimiser steps at MicroDiT_XL_2 widths (the
+    recipe of the 8-step test: batches 100 .. 349 of the YAML's schedule, batch 4, recorded noise) against the series recorded
+    from the UNMODIFIED reference (oracle/gen_golden.py xl2_curve_250 -> tests/golden/xl2_curve_250.npz, ~30 min of 6 host
+    threads; /root/reference/micro_diffusion/models/model.py:181-210, train.py:29-43,85-86).
+    Asserted: the mean loss of EVERY 25-step window within 1 % of the reference's, the whole-series mean within 0.5 %, the
+    pre-clip gradient norm within 5 % in the median, and the 250-step weight update (final - initial) of slices of the six named
+    tensors: cosine >= 0.99 with the reference's update, size within 5 %."""
+    got, ref, rel, gns, gref, grel, upd = _xl2_series("xl2_curve_250.npz")
+    n = len(ref) // 25
+    wg, wr = got[:n * 25].reshape(n, 25).mean(1), ref[:n * 25].reshape(n, 25).mean(1)
+    wrel = np.abs(wg - wr) / wr
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/xl2_curve_250steps.json", "w") as fh:
+        json.dump({"window_mean_hip": wg.tolist(), "window_mean_ref": wr.tolist(), "window_rel": wrel.tolist(),
+                   "series_mean_rel": float(abs(got.mean() - ref.mean()) / ref.mean()), "per_step_rel_median": float(np.median(rel)),
+                   "per_step_rel_p95": float(np.percentile(rel, 95)), "per_step_rel_max": float(rel.max()),
+                   "gnorm_rel_median": float(np.median(grel)), "gnorm_rel_p95": float(np.percentile(grel, 95)), "weight_update": upd,
+                   "loss_hip": got.tolist(), "loss_ref": ref.tolist()}, fh, indent=1)
+    print("xl2 250 steps: 25-step window rel", np.round(wrel, 4), "series mean rel %.5f" % (abs(got.mean() - ref.mean()) / ref.mean()))
+    print("xl2 250 steps: per-step rel median %.4f p95 %.4f max %.4f; gnorm rel median %.4f p95 %.4f" %
+          (np.median(rel), np.percentile(rel, 95), rel.max(), np.median(grel), np.percentile(grel, 95)))
+    print("xl2 250 steps: weight updates", json.dumps(upd))
+    assert wrel.max() <= 0.01, wrel
+    assert abs(got.mean() - ref.mean()) / ref.mean() <= 0.005
+    assert np.median(grel) <= 0.05, np.median(grel)
+    for k, u in upd.items():
+        assert u["cosine"] >= 0.99 and 0.95 <= u["size_ratio"] <= 1.05, (k, u)
 
 
 def _steps(model, tr, cfg, n_steps, B, seed0):
