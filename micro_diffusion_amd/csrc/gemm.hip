@@ -635,9 +635,10 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (a->A_list) variant = MD_GEMM_PP256;
     if (variant == MD_GEMM_AUTO) {
         // W4 (round 6): the 4-wave 16x16x32 kernel where it measured ahead of PP256 -- K-contiguous x K-contiguous launches with
-        // more than one tile per workgroup and no CU hold (profiles/r6_w4_vs_pp256.txt); the md_gemm_args.cu_limit launches of the
+        // at least 192 tiles and no CU hold (profiles/r6_w4_vs_pp256.txt); the md_gemm_args.cu_limit launches of the
         // data-parallel step keep PP256 and its split-K tail
-        if (md_gemm_w4_eligible(a) && tiles256 > 256 && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4"))
+        const char* w4min = getenv("MD_GEMM_W4_MIN_TILES");            // (A/B runs; default: the launches PP256 used to take)
+        if (md_gemm_w4_eligible(a) && tiles256 >= (w4min ? atoi(w4min) : 192) && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4"))
             variant = MD_GEMM_W4;
         else if (md_gemm_pp_eligible(a) && tiles256 >= 192)
             variant = MD_GEMM_PP256;

@@ -67,58 +67,85 @@ struct W4Tile {
     const char* gbase;         // &gate[0, n0] or nullptr
 };
 
-// Epilogue of rows 16 I .. 16 I + 15 of the wave's 128 x 128 tile (origin (wrow, wcol) inside the 256 x 256 tile).
-// Out of the MFMAs a lane owns 4 consecutive columns of a row per 16 x 16 block; the row group goes through one 4 KiB half of the
-// wave's private LDS slab (two halves alternate, so the writes of group I + 1 do not wait for the reads of group I):
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue.  Out of the MFMAs a lane owns 4 consecutive columns of a row per 16 x 16 block; a row group (16 rows x the wave's 128
+// columns) goes through one 4 KiB half of the wave's private LDS slab:
 //   write: bf16 pairs, 8 bytes at  row * 256 + ((32 j + 8 g) ^ (row << 4))     (row = lane % 16, g = lane / 16; 2-way store conflicts)
 //   read : 16 bytes (8 columns) at rr * 256 + ((16 c) ^ (rr << 4)),  rr = 4 t + lane / 16, c = lane % 16   (conflict-free)
 // so lane (rr, c) ends with columns 8 c .. 8 c + 7 of row rr and a store instruction writes 4 rows x 256 contiguous bytes.
+// The groups are software-pipelined over the two slab halves: group I's four reads are issued, group I + 1 is converted and written
+// to the other half while they fly, then group I is finished and stored (the first version waited for every read separately: 32
+// serialized LDS round trips per tile).  Per-lane offsets are formed once per tile (W4EpiLane); rows advance by scalar arithmetic.
 // bf16(acc) first (= what nn.Linear returns under autocast), then the fused arithmetic on that value, as in gemm_pp.hip.
-// WAIT_LOADS (the first row group): every VM load issued so far -- the k-loop's staging loads, this group's operand loads -- is
-// waited for before the first store is issued; the next k-tile's LDS writes then need no vmcnt (gen_w4_acc.py, FRESH).
-// Operands of the fused epilogues for row group I, in the store-side layout (lane = 8 columns of row 4 t + lane / 16).  ONE register
-// set, refreshed in place: as soon as step t of group I has consumed its piece, the same registers request piece t of group I + 1
-// (a whole row group of latency cover without a second set -- hipcc's 92 registers do not hold two).
+// Before the FIRST store of a tile every VM load issued so far (the k-loop's staging loads, the first operand requests) is waited
+// for: the next k-tile's LDS writes then need no vmcnt (gen_w4_acc.py, FRESH) and no store ever stands between a load and its wait.
+// ---------------------------------------------------------------------------------------------------------------------
+struct W4EpiLane {
+    unsigned wr[8];      // slab write offsets of the lane's 8-byte piece of column fragment j (without the half)
+    unsigned rd[4];      // slab read offsets of step t
+    unsigned oc, oc2, oo, og;   // global byte offsets of (row lane / 16, column 8 (lane % 16)) under ldc / ldc2 / the operand's ld; gate: column only
+    int rg, c8;          // lane / 16 and the first of the lane's 8 columns, both wave-tile-relative (predicates of ragged tiles)
+};
+// Operands of the fused epilogues for one row group, in the store-side layout.  ONE register set, refreshed in place: as soon as step
+// t of group I has consumed its piece, the same registers request piece t of group I + 1.
 struct W4Ops {
     uint4 v[4];
     uint4 gq;
 };
-template <int EPI, int I>
-__device__ __forceinline__ void w4_epi_ops(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, int wrow, int wcol, int lane_in, W4Ops& o) {
-    if constexpr (EPI == PP_E_RES || w4_is_dact(EPI)) {
-        int lane = lane_in;
-        asm volatile("" : "+v"(lane));
-        const int r = lane & 15, g = lane >> 4;
-        const int c8 = wcol + r * 8;
-        const unsigned ldo = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
-        const int mlast = et.mlim - 1;
-        const unsigned coff = (unsigned)(c8 < et.nlim ? c8 : 0);
+
+template <int EPI>
+__device__ __forceinline__ void w4_epi_lane(const md_gemm_args& p, const W4Tile& et, int wcol, int lane_in, W4EpiLane& L) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));               // formed per tile: nothing of it lives across the k-loop
+    const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = wrow + 16 * I + 4 * t + g;
-            o.v[t] = *reinterpret_cast<const uint4*>(et.opbase + ((unsigned)(row < mlast ? row : mlast) * ldo + coff) * 2u);
-        }
-        o.gq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
-        if (EPI == PP_E_RES && et.gbase) {
-            int r0 = et.m0 + wrow + 16 * I;                           // wave-uniform: rows_per_sample % 64 == 0 -> one gate row per group
-            r0 = r0 < w.M - 1 ? r0 : w.M - 1;
-            const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
-            o.gq = *reinterpret_cast<const uint4*>(et.gbase + ((size_t)(srow * (unsigned)p.ldg) + coff) * 2);
-        }
+    for (int j = 0; j < 8; ++j) L.wr[j] = (unsigned)(r * 256 + ((32 * j + 8 * g) ^ (r << 4)));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) L.rd[t] = (unsigned)((4 * t + g) * 256 + ((16 * r) ^ ((4 * t + g) << 4)));
+    L.rg = g;
+    L.c8 = r * 8;
+    const int cc = wcol + r * 8 < et.nlim ? r * 8 : 0;           // (ragged tiles: a column inside the matrix for the operand requests)
+    L.oc = (unsigned)(g * (int)p.ldc + r * 8) * 2u;
+    L.oc2 = (unsigned)(g * (int)p.ldc2 + r * 8) * 2u;
+    L.oo = (unsigned)(g * (int)(EPI == PP_E_RES ? p.ldr : p.ldaux) + cc) * 2u;
+    L.og = (unsigned)cc * 2u;
+}
+
+// Wave-uniform row cursors of the epilogue (SGPR pairs, stepped by 4 rows): first byte of the wave tile's current 4-row step in C, C2
+// and the operand matrix.  (Formed per step from the tile base, the 32 x 3 pointers were all kept live: 130-220 SGPR spills.)
+struct W4Rows {
+    char* c;
+    char* c2;
+    const char* op;       // the NEXT row group's step t (the operands are requested one group ahead)
+    int64_t sc, sc2, so;  // bytes per 4 rows
+};
+
+// request the fused-epilogue operands of row group I (rows clamped into the matrix)
+template <int EPI, bool INTERIOR>
+__device__ __forceinline__ void w4_epi_req(const md_gemm_args& p, const W4Tile& et, const W4EpiLane& L, const char* oprow, int row0, int wcol, uint4& dst) {
+    if (INTERIOR) {
+        dst = *reinterpret_cast<const uint4*>(oprow + L.oo);       // oprow = &op[wave tile row row0, wave tile column 0]
+    } else {                                                          // ragged tile: every lane's row clamped into the matrix
+        const int64_t ldo = EPI == PP_E_RES ? p.ldr : p.ldaux;
+        const int row = row0 + L.rg < et.mlim - 1 ? row0 + L.rg : et.mlim - 1;
+        dst = *reinterpret_cast<const uint4*>(et.opbase + ((int64_t)row * ldo + wcol) * 2 + L.og);
+    }
+}
+template <int EPI, int I>
+__device__ __forceinline__ void w4_epi_gate(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, const W4EpiLane& L, int wrow, int wcol, uint4& gq) {
+    gq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0
+    if (et.gbase) {
+        int r0 = et.m0 + wrow + 16 * I;                               // wave-uniform: rows_per_sample % 64 == 0 -> one gate row per group
+        r0 = r0 < w.M - 1 ? r0 : w.M - 1;
+        const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
+        gq = *reinterpret_cast<const uint4*>(et.gbase + ((int64_t)srow * p.ldg + wcol) * 2 + L.og);
     }
 }
 
-template <int EPI, int I, bool WAIT_LOADS>
-__device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, unsigned char* slab, int wrow, int wcol, int lane_in,
-                                            W4Ops& ops) {
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));               // lane geometry is recomputed per row group: nothing of it is hoisted out of the tile loop
-    const int r = lane & 15, g = lane >> 4;
+// convert row group I and write it to its slab half
+template <int I>
+__device__ __forceinline__ void w4_epi_write(unsigned char* slab, const W4EpiLane& L) {
     unsigned char* half = slab + (I & 1) * 4096;
-    const int c8 = wcol + r * 8;                                       // first column of this lane's 8 (tile-relative)
-    const bool cok = c8 < et.nlim;
-    uint4 (&opv)[4] = ops.v;
-    const uint4 gq = ops.gq;
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
         float a[16];
@@ -127,21 +154,24 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const w4_u32x2 v = {cvt_pk_bf16(a[4 * q], a[4 * q + 1]), cvt_pk_bf16(a[4 * q + 2], a[4 * q + 3])};
-            *reinterpret_cast<w4_u32x2*>(half + r * 256 + (((32 * (4 * jh + q)) + 8 * g) ^ (r << 4))) = v;
+            *reinterpret_cast<w4_u32x2*>(half + L.wr[4 * jh + q]) = v;
         }
     }
-    if constexpr (WAIT_LOADS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ldc = (unsigned)p.ldc;
+}
+
+// finish row group I: T[t] = its four slab reads (issued before group I + 1 was written); fused arithmetic; stores
+template <int EPI, int I, bool INTERIOR>
+__device__ __forceinline__ void w4_epi_store(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, const W4EpiLane& L, int wrow, int wcol,
+                                             const w4_u32x4 (&Tv)[4], W4Ops& ops, W4Rows& R) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int rr = 4 * t + g;
-        const w4_u32x4 Tv = *reinterpret_cast<const w4_u32x4*>(half + rr * 256 + ((16 * r) ^ (rr << 4)));
-        const uint4 T = make_uint4(Tv.x, Tv.y, Tv.z, Tv.w);
-        const int row = wrow + 16 * I + rr;
-        const bool ok = cok && row < et.mlim;
+        const uint4 T = make_uint4(Tv[t].x, Tv[t].y, Tv[t].z, Tv[t].w);
+        const int row0 = wrow + 16 * I + 4 * t;                      // wave-uniform: first row of the step's four
+        const bool ok = INTERIOR || (wcol + L.c8 < et.nlim && row0 + L.rg < et.mlim);
+        char* const crow = R.c;
         uint4 out = T;
         if constexpr (EPI == PP_E_BF16 || EPI == PP_E_RES || EPI == PP_E_BF16_GELU) {
-            if (et.c2base && ok) *reinterpret_cast<uint4*>(et.c2base + ((unsigned)row * (unsigned)p.ldc2 + (unsigned)c8) * 2u) = T;
+            if (et.c2base && ok) *reinterpret_cast<uint4*>(R.c2 + L.oc2) = T;
         }
         if constexpr (EPI == PP_E_BF16_GELU) {
             float v[8];
@@ -167,10 +197,11 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
             }
             out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
             if (et.c2base && ok)
-                *reinterpret_cast<uint4*>(et.c2base + ((unsigned)row * (unsigned)p.ldc2 + (unsigned)c8) * 2u) =
+                *reinterpret_cast<uint4*>(R.c2 + L.oc2) =
                     make_uint4(cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3]), cvt_pk_bf16(dv[4], dv[5]), cvt_pk_bf16(dv[6], dv[7]));
         } else if constexpr (EPI == PP_E_RES) {
-            const unsigned lw[4] = {T.x, T.y, T.z, T.w}, rw[4] = {opv[t].x, opv[t].y, opv[t].z, opv[t].w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
+            const uint4 gq = ops.gq;
+            const unsigned lw[4] = {T.x, T.y, T.z, T.w}, rw[4] = {ops.v[t].x, ops.v[t].y, ops.v[t].z, ops.v[t].w}, gw[4] = {gq.x, gq.y, gq.z, gq.w};
             unsigned ow[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
@@ -183,14 +214,14 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
         } else if constexpr (EPI == PP_E_DACT_MUL) {
             float v[8], ax[8];
             unpack8(T, v);
-            unpack8(opv[t], ax);
+            unpack8(ops.v[t], ax);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= ax[e];
             out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
         } else if constexpr (EPI == PP_E_DACT_GELU) {
             float v[8], ax[8];
             unpack8(T, v);
-            unpack8(opv[t], ax);
+            unpack8(ops.v[t], ax);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f32x2 d = dgelu_erf_2(f32x2{ax[e], ax[e + 1]});
@@ -202,29 +233,63 @@ __device__ __forceinline__ void w4_epi_rows(const md_gemm_args& p, const PPPlan&
 #ifdef W4_X_NOSTORE      // experiment: everything but the stores (the result is kept alive)
         asm volatile("" : : "v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
 #else
-        if (ok) *reinterpret_cast<uint4*>(et.cbase + ((unsigned)row * ldc + (unsigned)c8) * 2u) = out;
+        if (ok) *reinterpret_cast<uint4*>(crow + L.oc) = out;
 #endif
-        if constexpr ((EPI == PP_E_RES || w4_is_dact(EPI)) && I < 7) {     // this piece is consumed: request the next row group's
-            const unsigned ldo = EPI == PP_E_RES ? (unsigned)p.ldr : (unsigned)p.ldaux;
-            const int mlast = et.mlim - 1, nrow = row + 16;
-            opv[t] = *reinterpret_cast<const uint4*>(et.opbase + ((unsigned)(nrow < mlast ? nrow : mlast) * ldo + (unsigned)(cok ? c8 : 0)) * 2u);
-        }
+        if constexpr ((EPI == PP_E_RES || w4_is_dact(EPI)) && I < 7)      // this piece is consumed: request the next row group's
+            w4_epi_req<EPI, INTERIOR>(p, et, L, R.op, row0 + 16, wcol, ops.v[t]);
+        R.c += R.sc;
+        R.c2 += R.sc2;
+        R.op += R.so;
     }
-    if constexpr (EPI == PP_E_RES && I < 7) {
-        if (et.gbase) {
-            int r0 = et.m0 + wrow + 16 * (I + 1);
-            r0 = r0 < w.M - 1 ? r0 : w.M - 1;
-            const unsigned srow = w.rps_shift >= 0 ? (unsigned)r0 >> w.rps_shift : (unsigned)r0 / (unsigned)p.rows_per_sample;
-            ops.gq = *reinterpret_cast<const uint4*>(et.gbase + ((size_t)(srow * (unsigned)p.ldg) + (unsigned)(cok ? c8 : 0)) * 2);
-        }
-    }
+    if constexpr (EPI == PP_E_RES && I < 7) w4_epi_gate<EPI, I + 1>(p, w, et, L, wrow, wcol, ops.gq);
 }
 
-// amdgpu_num_vgpr(92), not 96: when hipcc spills SGPRs (the gated-residual instantiations do) it takes the last allowed VGPR for the
-// spill lanes and was seen to hand out the two registers ABOVE the limit as ordinary temporaries -- v96 / v97, the first staging
-// register.  v[92:95] are the guard band; scripts/check_w4_asm.py (tests/test_build_static.py) audits every build.
+template <int I>
+__device__ __forceinline__ void w4_epi_read(unsigned char* slab, const W4EpiLane& L, w4_u32x4 (&Tv)[4]) {
+    unsigned char* half = slab + (I & 1) * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Tv[t] = *reinterpret_cast<const w4_u32x4*>(half + L.rd[t]);
+}
+
+template <int EPI, bool INTERIOR>
+__device__ __forceinline__ void w4_epilogue(const md_gemm_args& p, const PPPlan& w, const W4Tile& et, unsigned char* slab, int wrow, int wcol, int lane) {
+    W4EpiLane L;
+    w4_epi_lane<EPI>(p, et, wcol, lane, L);
+    W4Ops ops;
+    W4Rows R;
+    const int64_t ldo = EPI == PP_E_RES ? p.ldr : p.ldaux;
+    R.sc = 8 * p.ldc;
+    R.sc2 = 8 * p.ldc2;
+    R.so = 8 * ldo;
+    R.c = et.cbase + ((int64_t)wrow * p.ldc + wcol) * 2;
+    R.c2 = et.c2base ? et.c2base + ((int64_t)wrow * p.ldc2 + wcol) * 2 : nullptr;
+    R.op = nullptr;
+    if constexpr (EPI == PP_E_RES || w4_is_dact(EPI)) {
+        R.op = et.opbase + ((int64_t)wrow * ldo + wcol) * 2;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w4_epi_req<EPI, INTERIOR>(p, et, L, R.op, wrow + 4 * t, wcol, ops.v[t]);
+            R.op += R.so;
+        }
+        if constexpr (EPI == PP_E_RES) w4_epi_gate<EPI, 0>(p, w, et, L, wrow, wcol, ops.gq);
+    }
+    w4_u32x4 Tv[4];
+    w4_epi_write<0>(slab, L);
+#define W4_EPI_STEP(I)                                                                                                  \
+    w4_epi_read<I>(slab, L, Tv);                                                                                        \
+    if constexpr ((I) < 7) w4_epi_write<((I) < 7 ? (I) + 1 : 7)>(slab, L);                                               \
+    if constexpr ((I) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    w4_epi_store<EPI, I, INTERIOR>(p, w, et, L, wrow, wcol, Tv, ops, R);
+    W4_EPI_STEP(0) W4_EPI_STEP(1) W4_EPI_STEP(2) W4_EPI_STEP(3) W4_EPI_STEP(4) W4_EPI_STEP(5) W4_EPI_STEP(6) W4_EPI_STEP(7)
+#undef W4_EPI_STEP
+}
+
+// amdgpu_num_vgpr(144): hipcc's values that live across the k-loop are below v96 by construction (every k-loop statement clobbers
+// v[96:255]); inside an epilogue it may use v[96:143], which hold nothing then (gen_w4_acc.py register plan).  A budget of 96 was
+// overrun -- not spilled -- by the instantiations with the heaviest epilogues (v96 / v97 handed out as temporaries: then the first
+// staging register).  scripts/check_w4_asm.py (tests/test_build_static.py) audits every build for v144+ / accumulator use.
 template <int BKC, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(92))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_BREG + 4 * W4_SLAB];   // 160 KiB: the whole LDS of a CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,13 +440,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(92))) void gemm
             asm volatile("s_nop 15\n\ts_nop 15");      // MFMA result -> v_accvgpr_read wait states (the last MFMA was just issued)
 #ifndef W4_X_NOEPI
             unsigned char* const slab = smem + 2 * W4_BREG + wave * W4_SLAB;
-            const int wrow = wr * 128, wcol = wc * 128;
-            W4Ops ops;
-            w4_epi_ops<EPI, 0>(p, w, et, wrow, wcol, lane, ops);
-            w4_epi_rows<EPI, 0, true>(p, w, et, slab, wrow, wcol, lane, ops);  w4_epi_rows<EPI, 1, false>(p, w, et, slab, wrow, wcol, lane, ops);
-            w4_epi_rows<EPI, 2, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 3, false>(p, w, et, slab, wrow, wcol, lane, ops);
-            w4_epi_rows<EPI, 4, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 5, false>(p, w, et, slab, wrow, wcol, lane, ops);
-            w4_epi_rows<EPI, 6, false>(p, w, et, slab, wrow, wcol, lane, ops); w4_epi_rows<EPI, 7, false>(p, w, et, slab, wrow, wcol, lane, ops);
+            if (et.mlim >= PT && et.nlim >= PT) w4_epilogue<EPI, true>(p, w, et, slab, wr * 128, wc * 128, lane);     // interior tile: no predicates
+            else w4_epilogue<EPI, false>(p, w, et, slab, wr * 128, wc * 128, lane);
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

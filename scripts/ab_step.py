@@ -35,7 +35,7 @@ def main():
             kv = dict(o.split("=") for o in opts.split(",") if o)
             for k in base:
                 setattr(eng, k, base[k])
-            for k in [k for k in os.environ if k.startswith("MD_GEMM_NO_")]:
+            for k in [k for k in os.environ if k.startswith("MD_GEMM_")]:
                 del os.environ[k]
             for k, val in kv.items():
                 if k.startswith("env."):                # library switches read with getenv at every launch (e.g. env.MD_GEMM_NO_W4=1)

@@ -3,12 +3,17 @@
 Register plan of the kernel (one wave per SIMD, the whole 512-register file):
     a[0:255]    64 accumulator blocks of 16 x 16 fp32: block (i, j) = a[4 (8 i + j) : +3] (row fragment i, column fragment j of the wave's
                 128 x 128 tile; v_mfma_f32_16x16x32_bf16 with swapped operands, D = B A^T: lane l holds row l % 16, columns 4 (l / 16) + r)
-    v[96:159]   staging registers ST[x] = v[96 + 4 x : +3]: pieces 0..7 of the A k-tile, 8..15 of the B k-tile (16 bytes per lane each)
-    v[160:223]  A fragments FA[set][i] = v[160 + 32 set + 4 i : +3], i = 0..7: set ks of the k-tile's two 32-deep k-steps
-    v[224:255]  B fragments FB[slot][q] = v[224 + 16 slot + 4 q : +3]: a k-step is multiplied in two HALVES of 32 MFMAs (column fragments
-                j = 4 h + q); half n of the stream uses slot n % 2 while the other slot is re-read
-    v[0:95]     hipcc's (addresses, loop state, the epilogue): the kernel carries amdgpu_num_vgpr(96), which keeps the compiler out of
-                v[96:255]; the registers above are named literally and listed as clobbers (that also sizes the kernel descriptor).
+    v[96:127]   A fragments of k-step 1: FA[1][i] = v[96 + 4 i : +3], i = 0..7        } dead while an epilogue runs (re-read in H1 / H0
+    v[128:143]  B fragments, slot 1:     FB[1][q] = v[128 + 4 q : +3]                  } before their next use)
+    v[144:207]  staging registers ST[x] = v[144 + 4 x : +3]: pieces 0..7 of the A k-tile, 8..15 of the B k-tile (16 bytes per lane each)
+    v[208:239]  A fragments of k-step 0: FA[0][i]
+    v[240:255]  B fragments, slot 0:     FB[0][q].  A k-step is multiplied in two HALVES of 32 MFMAs (column fragments j = 4 h + q);
+                half n of the stream uses slot n % 2 while the other slot is re-read
+    v[0:95]     hipcc's across the k-loop (addresses, loop state): every k-loop statement clobbers v[96:255], so nothing of the compiler's
+                can live there across one.  Inside an epilogue hipcc may spread into v[96:143] (amdgpu_num_vgpr(144): it was seen to overrun
+                a lower budget instead of spilling, into what then were the staging registers); scripts/check_w4_asm.py audits that no
+                compiler instruction names v144+ or an accumulator register.  The registers above are named literally and listed as
+                clobbers (that also sizes the kernel descriptor).
 Why asm: handed the same stream as plain loads / LDS accesses (or as asm with tied "+v" operands), hipcc gave every re-load of a staging
 or fragment register a fresh physical register, ran out of registers and spilled staging registers behind a vmcnt(0) in the k-loop; and
 compiler-owned accumulators that fill the accumulator file exactly were spilled at every loop header.
@@ -35,9 +40,13 @@ FLAGS = set(sys.argv[2:])
 OUT = sys.argv[1] if len(sys.argv) > 1 else None
 
 V0 = 96
-ST = lambda x: f"v[{V0 + 4 * x}:{V0 + 4 * x + 3}]"
-FA = lambda s, i: f"v[{160 + 32 * s + 4 * i}:{163 + 32 * s + 4 * i}]"
-FB = lambda s, q: f"v[{224 + 16 * s + 4 * q}:{227 + 16 * s + 4 * q}]"
+# A set 1 and B slot 1 are DEAD while the epilogue runs (re-read in H0 / H1 before their next use): they sit lowest, right above hipcc's
+# registers, so that a compiler that overruns its budget in an epilogue (it does: amdgpu_num_vgpr is not a hard limit) lands in them
+FA_BASE = {1: 96, 0: 208}
+FB_BASE = {1: 128, 0: 240}
+ST = lambda x: f"v[{144 + 4 * x}:{147 + 4 * x}]"
+FA = lambda s, i: f"v[{FA_BASE[s] + 4 * i}:{FA_BASE[s] + 4 * i + 3}]"
+FB = lambda s, q: f"v[{FB_BASE[s] + 4 * q}:{FB_BASE[s] + 4 * q + 3}]"
 ACC = lambda i, j: f"a[{4 * (8 * i + j)}:{4 * (8 * i + j) + 3}]"
 BUF = 32768          # bytes of one operand of one k-tile buffer
 FRAG = 2048          # bytes of 16 rows of a buffer
@@ -85,7 +94,7 @@ def reads_b(o, bkc, slot, ks, h, buf):
         return [f"ds_read_b128 {FB(slot, q)}, {o(f'ad.adB[{ks}]')} offset:{buf * BUF + (4 * h + q) * FRAG}" for q in range(4)]
     out = []
     for q in range(4):
-        lo = 224 + 16 * slot + 4 * q
+        lo = FB_BASE[slot] + 4 * q
         ad = o(f"ad.adB[{4 * h + q}]")
         out.append(f"ds_read_b64_tr_b16 v[{lo}:{lo + 1}], {ad} offset:{buf * BUF + ks * 16384}")
         out.append(f"ds_read_b64_tr_b16 v[{lo + 2}:{lo + 3}], {ad} offset:{buf * BUF + ks * 16384 + 2048}")
