@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MD_ABI_VERSION 5
+#define MD_ABI_VERSION 6
 int md_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM */
@@ -194,9 +194,21 @@ int md_qkln_fwd(void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width
 int md_qkln_bwd(void* d, int64_t ldd, int64_t dcol0, const void* y, int64_t ldy, int64_t ycol0, int64_t rows,
                 int64_t width, int32_t nseg, int64_t dseg_stride, int64_t yseg_stride, const float* rstd, hipStream_t stream);
 
+/* Head-major forms (ABI 6).  The forward reads the row-major segments like md_qkln_fwd and writes the normalised values
+ * HEAD-MAJOR into a separate buffer: element (row = b * S + s, segment g, column c = h * hd + e) goes to
+ * out[g * out_seg_stride + ((b * H + h) * S + s) * hd + e], H = width / hd -- one contiguous [S, hd] block per (sample, head), which is
+ * what the attention kernels read (md_attn_args.hsq / hsk); buf is left untouched.  The backward reads dL/dy (written head-major by
+ * md_attn_bwd) and y in that layout and writes dL/dx row-major into d (the operand of the qkv / q / kv weight- and data-gradient
+ * GEMMs).  rows % S == 0.  The [B, N, 3, H, hd] reshape + permute of utils.py:177-182 (116-121) is the layout freedom used. */
+int md_qkln_fwd_hm(const void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, int32_t nseg, int64_t seg_stride,
+                   void* out, int64_t out_seg_stride, int64_t S, int32_t hd, float* rstd_out, float eps, hipStream_t stream);
+int md_qkln_bwd_hm(const void* dy, int64_t dy_seg_stride, const void* y, int64_t y_seg_stride, void* d, int64_t ldd, int64_t dcol0,
+                   int64_t dseg_stride, int64_t rows, int64_t width, int32_t nseg, int64_t S, int32_t hd, const float* rstd,
+                   hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------- attention */
 /* softmax(scale * Q K^T) V per (batch, head), non-causal, no mask.  Row r of head h of batch b of X lives at
- * X + b*sX + r*ldX + h*hd (bf16), so packed qkv / kv projection buffers are addressed in place.
+ * X + b*sX + r*ldX + h*hsX (bf16; hsX = hd unless set), so packed qkv / kv projection buffers are addressed in place.
  * lse / delta: f32 [B, H, Sq].  Replaces F.scaled_dot_product_attention (utils.py:127-132,188-193) + backward. */
 typedef struct md_attn_args {
     const void *q, *k, *v;
@@ -212,13 +224,15 @@ typedef struct md_attn_args {
     int32_t hd;        /* 32 or 64 */
     int32_t bwd_split; /* backward kernel: 0 = the library picks (one fused launch per (batch, head) for Sq, Skv <= 256; the streaming
                           pair (5) for longer sequences);
-                          forced (tests, A/B runs): 1 = the dQ + dK/dV pair, 2 = fused with Q, dO, K, V in LDS together (Sq, Skv
-                          <= 256 only), 3 = fused in two phases on half the LDS (longer sequences: one launch per <= 256 x 256 block
-                          pair, every output block with one writer at a time, dq / dk / dv accumulated in place), 4 = the same with
-                          dK / dV as two passes for every
-                          size (3 does that for the 256-row buckets only), 5 = the streaming pair (the pair's two launches with
-                          128-row chunks, register prefetch and 8-wave workgroups: the library's choice when Sq or Skv > 256).
-                          A forced variant that does not cover the problem returns -1 and launches nothing. */
+                          forced (tests, A/B runs): 2 = fused with Q, dO, K, V in LDS together, 3 = fused in two phases on half the
+                          LDS, 4 = the same with dK / dV as two passes for every size (3 does that for the 256-row buckets only)
+                          -- all three for Sq, Skv <= 256 only; 5 = the streaming pair (two launches, 128-row chunks, register
+                          prefetch, 8-wave workgroups; any size).  A forced variant that does not cover the problem returns -1 and
+                          launches nothing.  (1, the round-4 dQ + dK/dV pair, and the block-pair form of 3 / 4 for long sequences
+                          were removed in ABI 6.) */
+    /* ABI 6: element offset of head h inside its row, per tensor (0 = hd: heads packed side by side in the row).  A head-major
+     * tensor [B, H, S, hd] (what md_qkln_fwd_hm writes) is ldX = hd, sX = H * S * hd, hsX = S * hd. */
+    int64_t hsq, hsk, hsv, hso, hsdq, hsdk, hsdv, hsdo;
 } md_attn_args;
 
 int md_attn_fwd(const md_attn_args* a, hipStream_t stream);

@@ -179,23 +179,6 @@ __device__ __forceinline__ void store_rows(bf16* dst_row, const f32x16 (&acc)[HD
         }
 }
 
-// The same with the bf16 value already at the destination added in (block rounds of the long-sequence backward).
-template <int HD>
-__device__ __forceinline__ void store_rows_acc(bf16* dst_row, const f32x16 (&acc)[HD / 32], float mul, int lane) {
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int di = 0; di < HD / 32; ++di)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16* d = dst_row + di * 32 + 8 * g + 4 * hh;
-            const bf16x4 old = ld_bf16x4(d);
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[di][4 * g + e] * mul + bf2f(old[e]));
-            st_bf16x4(d, o);
-        }
-}
-
 // (Measured and dropped: capping this kernel at 128 VGPRs -- 117 without a spill at head_dim 64, 4 waves / SIMD instead of 3 --
 // made the 2-wave instantiation 15 % SLOWER in the step, 142.7 -> 164.9 us; the allocation the compiler picks on its own keeps
 // more of a phase's loads in flight.  profiles/r2_attention_two_phase_bwd.txt.)
@@ -209,9 +192,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool qvalid = q < p.Sq;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
 
     bf16x8 qf[HD / 16];
 #pragma unroll
@@ -281,187 +264,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(md_attn_args p) {
       }
     }
     if (qvalid) {
-        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * p.hso + q * p.ldo;
         store_rows<HD>(O, oacc, 1.f / l, lane);
         if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = (m + __log2f(l)) * 0.6931471805599453f;   // natural log
-    }
-}
-
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(md_attn_args p) {
-    constexpr int PK = (HD + 8) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
-    const int hh = lane >> 5;
-    const int64_t b = blockIdx.z, h = blockIdx.y;
-    const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
-    const bool qvalid = q < p.Sq;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
-
-    bf16x8 qf[HD / 16], dof[HD / 16];
-#pragma unroll
-    for (int s = 0; s < HD / 16; ++s) {
-        if (qvalid) {
-            qf[s] = ld_bf16x8(Q + q * p.ldq + s * 16 + hh * 8);
-            dof[s] = ld_bf16x8(dO + q * p.lddo + s * 16 + hh * 8);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                qf[s][e] = f2bf(0.f);
-                dof[s][e] = f2bf(0.f);
-            }
-        }
-    }
-    const float lse = qvalid ? reinterpret_cast<const float*>(p.lse)[(b * p.H + h) * p.Sq + q] * LOG2E : 0.f;   // log2 domain (ds_cols)
-    const float c1 = p.scale * LOG2E;
-    // delta[q] = sum_d dO[q, d] * O[q, d]: this lane holds half of row q (its 8-wide d-chunks), the partner lane the rest
-    float dlt = 0.f;
-    if (qvalid) {
-        const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
-#pragma unroll
-        for (int s = 0; s < HD / 16; ++s) {
-            const bf16x8 ov = ld_bf16x8(O + s * 16 + hh * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dlt += bf2f(ov[e]) * bf2f(dof[s][e]);
-        }
-    }
-    dlt += __shfl_xor(dlt, 32, 64);
-    if (qvalid && lane < 32) reinterpret_cast<float*>(p.delta)[(b * p.H + h) * p.Sq + q] = dlt;   // for the dK/dV kernel
-    f32x16 dqacc[HD / 32];
-#pragma unroll
-    for (int di = 0; di < HD / 32; ++di)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqacc[di][r] = 0.f;
-
-    for (int64_t kbase = 0; kbase < p.Skv; kbase += STG) {
-        __syncthreads();
-        const int nst = (int)((p.Skv - kbase >= STG) ? STG : ((p.Skv - kbase + 31) / 32) * 32);
-        stage_pair<HD, STG * (HD / 8) / 64>(smem, smem + STG * PK, PK, K, p.ldk, V, p.ldv, kbase, p.Skv, nst, tid, nthreads);
-        __syncthreads();
-      for (int sub = 0; sub < STG / 32 && kbase + sub * 32 < p.Skv; ++sub) {
-        const int64_t key0 = kbase + sub * 32;
-        const unsigned char* sK = smem + sub * 32 * PK;
-        const unsigned char* sV = smem + STG * PK + sub * 32 * PK;
-        f32x16 sacc, dpacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sacc[r] = 0.f;
-            dpacc[r] = 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < HD / 16; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PK, s * 16, lane), qf[s], sacc, 0, 0, 0);
-            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, PK, s * 16, lane), dof[s], dpacc, 0, 0, 0);
-        }
-        ds_cols(sacc, dpacc, c1, lse, dlt, (int)(p.Skv - key0), hh);   // dS^T / scale
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const bf16x8 dsf = pack8(sacc, 8 * sp);
-#pragma unroll
-            for (int di = 0; di < HD / 32; ++di)
-                dqacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    tr_frag(sK, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dqacc[di], 0, 0, 0);
-        }
-      }
-    }
-    if (qvalid) {
-        bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-        store_rows<HD>(dQ, dqacc, p.scale, lane);
-    }
-}
-
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(md_attn_args p) {
-    constexpr int PK = (HD + 8) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG * PK + 2 * STG * 4];
-    float* sLseAll = reinterpret_cast<float*>(smem + 2 * STG * PK);
-    float* sDltAll = sLseAll + STG;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
-    const int hh = lane >> 5;
-    const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
-    const int64_t b = blockIdx.z, h = blockIdx.y;
-    const int64_t key = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
-    const bool kvalid = key < p.Skv;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
-    const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
-    const float* DLT = reinterpret_cast<const float*>(p.delta) + (b * p.H + h) * p.Sq;
-
-    bf16x8 kf[HD / 16], vf[HD / 16];
-#pragma unroll
-    for (int s = 0; s < HD / 16; ++s) {
-        if (kvalid) {
-            kf[s] = ld_bf16x8(K + key * p.ldk + s * 16 + hh * 8);
-            vf[s] = ld_bf16x8(V + key * p.ldv + s * 16 + hh * 8);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                kf[s][e] = f2bf(0.f);
-                vf[s][e] = f2bf(0.f);
-            }
-        }
-    }
-    f32x16 dkacc[HD / 32], dvacc[HD / 32];
-#pragma unroll
-    for (int di = 0; di < HD / 32; ++di)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dkacc[di][r] = 0.f;
-            dvacc[di][r] = 0.f;
-        }
-
-    for (int64_t qbase = 0; qbase < p.Sq; qbase += STG) {
-        __syncthreads();
-        const int nst = (int)((p.Sq - qbase >= STG) ? STG : ((p.Sq - qbase + 31) / 32) * 32);
-        stage_pair<HD, STG * (HD / 8) / 64>(smem, smem + STG * PK, PK, Q, p.ldq, dO, p.lddo, qbase, p.Sq, nst, tid, nthreads);
-        for (int i = tid; i < nst; i += nthreads) {
-            const bool v = qbase + i < p.Sq;
-            sLseAll[i] = v ? LSE[qbase + i] * LOG2E : 0.f;       // log2 domain (p_ds_rows)
-            sDltAll[i] = v ? DLT[qbase + i] : 0.f;
-        }
-        __syncthreads();
-      for (int sub = 0; sub < STG / 32 && qbase + sub * 32 < p.Sq; ++sub) {
-        const int64_t q0 = qbase + sub * 32;
-        const unsigned char* sQ = smem + sub * 32 * PK;
-        const unsigned char* sdO = smem + STG * PK + sub * 32 * PK;
-        const float* sLse = sLseAll + sub * 32;
-        const float* sDlt = sDltAll + sub * 32;
-        f32x16 sacc, dpacc;  // S[q][key], dP[q][key]: lane <-> key, regs <-> q
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sacc[r] = 0.f;
-            dpacc[r] = 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < HD / 16; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, PK, s * 16, lane), kf[s], sacc, 0, 0, 0);
-            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, PK, s * 16, lane), vf[s], dpacc, 0, 0, 0);
-        }
-        p_ds_rows<true, true>(sacc, dpacc, c1, sLse, sDlt, (int)(p.Sq - q0), hh);   // P, dS / scale
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const bf16x8 pf = pack8(sacc, 8 * sp);
-            const bf16x8 dsf = pack8(dpacc, 8 * sp);
-#pragma unroll
-            for (int di = 0; di < HD / 32; ++di) {
-                dvacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    tr_frag(sdO, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), pf, dvacc[di], 0, 0, 0);
-                dkacc[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    tr_frag(sQ, PK, 16 * sp + 4 * hh, 16 * sp + 8 + 4 * hh, di * 32, lane), dsf, dkacc[di], 0, 0, 0);
-            }
-        }
-      }
-    }
-    if (kvalid) {
-        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
-        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
-        store_rows<HD>(dK, dkacc, p.scale, lane);
-        store_rows<HD>(dV, dvacc, 1.f, lane);
     }
 }
 
@@ -526,9 +331,9 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) { 
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool qvalid = q < p.Sq;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
 
     ChunkRegs<HD, MAXIT> R;
     chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, 0, p.Skv, tid, nthreads);
@@ -602,7 +407,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(md_attn_args p) { 
         }
     }
     if (qvalid) {
-        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+        bf16* O = reinterpret_cast<bf16*>(p.o) + b * p.so + h * p.hso + q * p.ldo;
         store_rows<HD>(O, oacc, 1.f / l, lane);
         if (lane < 32 && p.lse) reinterpret_cast<float*>(p.lse)[(b * p.H + h) * p.Sq + q] = (m + __log2f(l)) * 0.6931471805599453f;   // natural log
     }
@@ -620,10 +425,10 @@ void attn_bwd_dq_stream_kernel(md_attn_args p) {
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t q = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool qvalid = q < p.Sq;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * p.hsdo;
 
     ChunkRegs<HD, MAXIT> R;
     chunk_load<HD, SCH, MAXIT>(R, K, p.ldk, V, p.ldv, 0, p.Skv, tid, nthreads);       // chunk 0 on its way before the row set-up
@@ -645,7 +450,7 @@ void attn_bwd_dq_stream_kernel(md_attn_args p) {
     const float c1 = p.scale * LOG2E;
     float dlt = 0.f;      // delta[q] = sum_d dO[q, d] * O[q, d]: this lane holds half of row q, the partner lane the rest
     if (qvalid) {
-        const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD + q * p.ldo;
+        const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * p.hso + q * p.ldo;
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
             const bf16x8 ov = ld_bf16x8(O + s * 16 + hh * 8);
@@ -701,7 +506,7 @@ void attn_bwd_dq_stream_kernel(md_attn_args p) {
         }
     }
     if (qvalid) {
-        bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+        bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * p.hsdq + q * p.lddq;
         store_rows<HD>(dQ, dqacc, p.scale, lane);
     }
 }
@@ -720,10 +525,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
     const int64_t b = blockIdx.z, h = blockIdx.y;
     const int64_t key = ((int64_t)blockIdx.x * nw + wave) * 32 + (lane & 31);
     const bool kvalid = key < p.Skv;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * p.hsdo;
     const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
     const float* DLT = reinterpret_cast<const float*>(p.delta) + (b * p.H + h) * p.Sq;
 
@@ -808,8 +613,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(md_attn_args p
         for (int sub = 0; sub < SCH / 32 && qbase + sub * 32 < p.Sq; ++sub) tile(sub, (int)(p.Sq - qbase - sub * 32));
     }
     if (kvalid) {
-        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
-        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * p.hsdk + key * p.lddk;
+        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * p.hsdv + key * p.lddv;
         store_rows<HD>(dK, dkacc, p.scale, lane);
         store_rows<HD>(dV, dvacc, 1.f, lane);
     }
@@ -837,11 +642,11 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
     const int hh = lane >> 5;
     const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
     const int64_t b = blockIdx.y, h = blockIdx.x;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
-    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * p.hsdo;
+    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * p.hso;
     const int nq32 = (int)((p.Sq + 31) / 32), nk32 = (int)((p.Skv + 31) / 32);
 
     // Staging: EVERY global load of the workgroup is issued before the first LDS write -- Q, dO, O (3 x ITQ) and K, V (2 x ITK)
@@ -943,7 +748,7 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
             }
         }
         if (q < p.Sq) {
-            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
+            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * p.hsdq + q * p.lddq;
             store_rows<HD>(dQ, dqacc, p.scale, lane);
         }
     }
@@ -997,8 +802,8 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
             }
         }
         if (key < p.Skv) {
-            bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
-            bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+            bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * p.hsdk + key * p.lddk;
+            bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * p.hsdv + key * p.lddv;
             store_rows<HD>(dK, dkacc, p.scale, lane);
             store_rows<HD>(dV, dvacc, 1.f, lane);
         }
@@ -1023,21 +828,12 @@ __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) void attn_bwd_fused_ke
 // nothing to overlap its load and store phases with.  Price: S = Q K^T and the exponentials of role 2 are formed twice
 // (20 instead of 16 MFMAs per tile pair).
 // ---------------------------------------------------------------------------------------------------------------------
-// Sequences longer than one image of this kernel (Sq or Skv > 256: the res-512 patch mixer, 1024 tokens, and its cross-attention,
-// 1024 x 77 -- /root/reference/configs/res_512_pretrain.yaml:24, utils.py:188-193): the problem is cut into nqb x nkb blocks of at most
-// 256 x 256.  Given the forward's log-sum-exp (and delta = rowsum(dO * O), a per-row quantity the kernel forms itself) the
-// contributions of the block pairs to dQ / dK / dV are INDEPENDENT sums, so one block pair is exactly this kernel's problem: the
-// host (launch_bwd_fused) launches it once per block pair with the pointers moved to the pair's rows, the pairs ordered so that
-// every output block has ONE writer at a time (stream order), and pairs after an output block's first add into it
-// (store_rows_acc; no atomics, deterministic).  lse_stride = rows per (batch, head) of the log-sum-exp array (the WHOLE Sq);
-// acc_flags bit 0: dQ of this launch accumulates, bit 1: dK / dV do.
+// Sequences longer than 256 rows run on the streaming pair (the block-pair form of round 5 -- one launch of this kernel per
+// <= 256 x 256 block pair, accumulating in place -- measured 1.6x slower and was removed in round 6).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int ATTN_BLK = 256;
-
 template <int HD, int SQP, int SKP, bool SPLIT2>
 __global__ __launch_bounds__((SQP > SKP ? SQP : SKP) * 2) __attribute__((amdgpu_waves_per_eu(SPLIT2 ? 4 : 3)))
-void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
-    const bool acc_q = acc_flags & 1, acc_kv = acc_flags & 2;
+void attn_bwd_fused2_kernel(md_attn_args p) {
     constexpr int PK = (HD + 8) * 2;
     constexpr int RMAX = SQP > SKP ? SQP : SKP;
     constexpr int NT = RMAX * 2;                                       // = blockDim.x: one wave per 32 rows of the taller side
@@ -1050,11 +846,11 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
     const int hh = lane >> 5;
     const float c1 = p.scale * LOG2E;        // scores -> log2 domain (ds_cols / p_ds_rows)
     const int64_t b = blockIdx.y, h = blockIdx.x;
-    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * HD;
-    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * HD;
-    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * HD;
-    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * HD;
-    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * HD;
+    const bf16* Q = reinterpret_cast<const bf16*>(p.q) + b * p.sq + h * p.hsq;
+    const bf16* K = reinterpret_cast<const bf16*>(p.k) + b * p.sk + h * p.hsk;
+    const bf16* V = reinterpret_cast<const bf16*>(p.v) + b * p.sv + h * p.hsv;
+    const bf16* dO = reinterpret_cast<const bf16*>(p.d_o) + b * p.sdo + h * p.hsdo;
+    const bf16* O = reinterpret_cast<const bf16*>(p.o) + b * p.so + h * p.hso;
     const int nq32 = (int)((p.Sq + 31) / 32), nk32 = (int)((p.Skv + 31) / 32);
 
     constexpr int CPR = HD / 8;
@@ -1062,7 +858,7 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
     u32x4 rk[ITK], rv[ITK];
     {
         // every global load of the workgroup in flight before the first LDS write (as in the single-phase kernel)
-        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * lse_stride;
+        const float* LSE = reinterpret_cast<const float*>(p.lse) + (b * p.H + h) * p.Sq;
         u32x4 rq[ITQ], rdo[ITQ], ro[ITQ];
         float rl[ITQ];
         const u32x4 z4 = {0u, 0u, 0u, 0u};
@@ -1160,9 +956,8 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
             }
         }
         if (q < p.Sq) {
-            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * HD + q * p.lddq;
-            if (acc_q) store_rows_acc<HD>(dQ, dqacc, p.scale, lane);
-            else store_rows<HD>(dQ, dqacc, p.scale, lane);
+            bf16* dQ = reinterpret_cast<bf16*>(p.dq) + b * p.sdq + h * p.hsdq + q * p.lddq;
+            store_rows<HD>(dQ, dqacc, p.scale, lane);
         }
     }
     // this wave's 32 key rows, while K and V are still in LDS
@@ -1187,8 +982,8 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
     // ---- P6 role 2: dK, dV for key rows wave * 32 ..
     if (krole) {
         const int64_t key = (int64_t)wave * 32 + (lane & 31);
-        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * HD + key * p.lddk;
-        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * HD + key * p.lddv;
+        bf16* dK = reinterpret_cast<bf16*>(p.dk) + b * p.sdk + h * p.hsdk + key * p.lddk;
+        bf16* dV = reinterpret_cast<bf16*>(p.dv) + b * p.sdv + h * p.hsdv + key * p.lddv;
         if (SPLIT2) {
             f32x16 acc[HD / 32];
             // pass 1: dV = P^T dO
@@ -1217,8 +1012,7 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
                 }
             }
             if (key < p.Skv) {
-                if (acc_kv) store_rows_acc<HD>(dV, acc, 1.f, lane);
-                else store_rows<HD>(dV, acc, 1.f, lane);
+                store_rows<HD>(dV, acc, 1.f, lane);
             }
             // pass 2: dK = dS^T Q
 #pragma unroll
@@ -1252,8 +1046,7 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
                 }
             }
             if (key < p.Skv) {
-                if (acc_kv) store_rows_acc<HD>(dK, acc, p.scale, lane);
-                else store_rows<HD>(dK, acc, p.scale, lane);
+                store_rows<HD>(dK, acc, p.scale, lane);
             }
         } else {
             f32x16 dkacc[HD / 32], dvacc[HD / 32];
@@ -1295,13 +1088,8 @@ void attn_bwd_fused2_kernel(md_attn_args p, int64_t lse_stride, int acc_flags) {
                 }
             }
             if (key < p.Skv) {
-                if (acc_kv) {
-                    store_rows_acc<HD>(dK, dkacc, p.scale, lane);
-                    store_rows_acc<HD>(dV, dvacc, 1.f, lane);
-                } else {
-                    store_rows<HD>(dK, dkacc, p.scale, lane);
-                    store_rows<HD>(dV, dvacc, 1.f, lane);
-                }
+                store_rows<HD>(dK, dkacc, p.scale, lane);
+                store_rows<HD>(dV, dvacc, 1.f, lane);
             }
         }
     }
@@ -1316,11 +1104,11 @@ inline int fused_bucket(int64_t S) { return S <= 64 ? 64 : S <= 96 ? 96 : S <= 2
 // the 64 x 64 bucket pair, where the single-phase kernel is 10 % ahead (two-wave workgroups: the five extra barriers cost more
 // than 6 instead of 4 resident workgroups return).
 template <int HD>
-void launch_bwd_fused_one(const md_attn_args* a, int variant, int bq, int bk, int64_t lse_stride, int acc_flags, hipStream_t stream) {
+void launch_bwd_fused_one(const md_attn_args* a, int variant, int bq, int bk, hipStream_t stream) {
     const dim3 grid((unsigned)a->H, (unsigned)a->B);
 #define FUSED(SQP, SKP) hipLaunchKernelGGL((attn_bwd_fused_kernel<HD, SQP, SKP>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
 #define FUSED2(SQP, SKP, SPL) \
-    hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a, lse_stride, acc_flags)
+    hipLaunchKernelGGL((attn_bwd_fused2_kernel<HD, SQP, SKP, SPL>), grid, dim3((SQP > SKP ? SQP : SKP) * 2), 0, stream, *a)
 #define SMALL(SQP, SKP)                          \
     do {                                         \
         if (variant == 2 || (variant == 0 && SQP == 64 && SKP == 64)) FUSED(SQP, SKP); \
@@ -1350,41 +1138,8 @@ void launch_bwd_fused_one(const md_attn_args* a, int variant, int bq, int bk, in
 template <int HD>
 bool launch_bwd_fused(const md_attn_args* a, int variant, hipStream_t stream) {
     const int bq = fused_bucket(a->Sq), bk = fused_bucket(a->Skv);
-    if (bq && bk) {
-        launch_bwd_fused_one<HD>(a, variant, bq, bk, a->Sq, 0, stream);
-        return true;
-    }
-    // Longer than one image: one launch per <= 256 x 256 block pair on the two-phase kernel (comment above attn_bwd_fused2_kernel).
-    // Order: rounds r = 0 .. n - 1 of the pairs (qb, (qb + r) mod n), n = max(nqb, nkb) -- within a round no two pairs share an
-    // output block, so a later "launch them side by side" form stays possible; the stream order alone already gives every
-    // output block one writer at a time.
-    if (variant == 2) return false;                               // the single-phase kernel has no block form
-    const int nqb = (int)((a->Sq + ATTN_BLK - 1) / ATTN_BLK), nkb = (int)((a->Skv + ATTN_BLK - 1) / ATTN_BLK);
-    const int n = nqb > nkb ? nqb : nkb;
-    if (n > 16) return false;                                     // > 4096 tokens: the kernel pair
-    unsigned q_written = 0, k_written = 0;                        // bit per block: an earlier pair already stored this output block
-    for (int r = 0; r < n; ++r)
-        for (int qb = 0; qb < nqb; ++qb) {
-            const int kb = (qb + r) % n;
-            if (kb >= nkb) continue;
-            const int64_t q0 = (int64_t)qb * ATTN_BLK, k0 = (int64_t)kb * ATTN_BLK;
-            md_attn_args c = *a;
-            c.q = static_cast<const bf16*>(a->q) + q0 * a->ldq;
-            c.d_o = static_cast<const bf16*>(a->d_o) + q0 * a->lddo;
-            c.o = static_cast<bf16*>(a->o) + q0 * a->ldo;
-            c.dq = static_cast<bf16*>(a->dq) + q0 * a->lddq;
-            c.lse = static_cast<float*>(a->lse) + q0;
-            c.k = static_cast<const bf16*>(a->k) + k0 * a->ldk;
-            c.v = static_cast<const bf16*>(a->v) + k0 * a->ldv;
-            c.dk = static_cast<bf16*>(a->dk) + k0 * a->lddk;
-            c.dv = static_cast<bf16*>(a->dv) + k0 * a->lddv;
-            c.Sq = a->Sq - q0 < ATTN_BLK ? a->Sq - q0 : ATTN_BLK;
-            c.Skv = a->Skv - k0 < ATTN_BLK ? a->Skv - k0 : ATTN_BLK;
-            const int flags = ((q_written >> qb) & 1) | (((k_written >> kb) & 1) << 1);
-            q_written |= 1u << qb;
-            k_written |= 1u << kb;
-            launch_bwd_fused_one<HD>(&c, variant ? variant : 3, fused_bucket(c.Sq), fused_bucket(c.Skv), a->Sq, flags, stream);   // (0 could pick the single-phase kernel, which cannot accumulate)
-        }
+    if (!bq || !bk) return false;                                 // longer than one image of the kernel: the streaming pair
+    launch_bwd_fused_one<HD>(a, variant, bq, bk, stream);
     return true;
 }
 
@@ -1431,13 +1186,25 @@ inline int waves_for(int64_t S) {
 inline bool attn_ok(const md_attn_args* a) {
     return a && a->q && a->k && a->v && a->o && a->B > 0 && a->H > 0 && a->Sq > 0 && a->Skv > 0 &&
            (a->hd == 32 || a->hd == 64) && a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0 &&
-           a->sq % 8 == 0 && a->sk % 8 == 0 && a->sv % 8 == 0 && a->so % 4 == 0;
+           a->sq % 8 == 0 && a->sk % 8 == 0 && a->sv % 8 == 0 && a->so % 4 == 0 && a->hsq % 8 == 0 && a->hsk % 8 == 0 &&
+           a->hsv % 8 == 0 && a->hso % 4 == 0 && a->hsdo % 8 == 0 && a->hsdq % 4 == 0 && a->hsdk % 4 == 0 && a->hsdv % 4 == 0;
+}
+
+// head strides of 0 = the packed default: head h of a row starts h * hd elements into it
+inline md_attn_args with_head_strides(const md_attn_args* a) {
+    md_attn_args c = *a;
+    int64_t* hs[8] = {&c.hsq, &c.hsk, &c.hsv, &c.hso, &c.hsdq, &c.hsdk, &c.hsdv, &c.hsdo};
+    for (int64_t* p : hs)
+        if (*p == 0) *p = c.hd;
+    return c;
 }
 
 }  // namespace
 
-extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
-    if (!attn_ok(a)) return MD_BAD_ARG;
+extern "C" int md_attn_fwd(const md_attn_args* a_in, hipStream_t stream) {
+    if (!attn_ok(a_in)) return MD_BAD_ARG;
+    const md_attn_args args = with_head_strides(a_in);
+    const md_attn_args* a = &args;
     static const bool fwd_stream = [] { const char* e = getenv("MD_ATTN_FWD_STREAM"); return !e || atoi(e) != 0; }();   // A/B: 0 = the phased kernel everywhere
     static const int fwd_stream_min = [] { const char* e = getenv("MD_ATTN_FWD_STREAM_MIN_SKV"); return e ? atoi(e) : 257; }();   // A/B
     if (fwd_stream && a->Skv >= fwd_stream_min && a->Sq >= 192) {
@@ -1472,35 +1239,25 @@ extern "C" int md_attn_fwd(const md_attn_args* a, hipStream_t stream) {
     return 0;
 }
 
-extern "C" int md_attn_bwd(const md_attn_args* a, hipStream_t stream) {
-    if (!attn_ok(a) || !a->d_o || !a->dq || !a->dk || !a->dv || !a->lse || !a->delta) return MD_BAD_ARG;
+// bwd_split: 0 = the library's rule (one fused launch per (batch, head) for Sq, Skv <= 256, the streaming pair beyond);
+// 2 / 3 / 4 force the fused kernel's single-phase / two-phase / two-phase SPLIT2 form (Sq, Skv <= 256 only: -1 otherwise, nothing
+// launched); 5 forces the streaming pair (any size).  (1 was the round-4 kernel pair, removed in round 6.)
+extern "C" int md_attn_bwd(const md_attn_args* a_in, hipStream_t stream) {
+    if (!attn_ok(a_in) || !a_in->d_o || !a_in->dq || !a_in->dk || !a_in->dv || !a_in->lse || !a_in->delta) return MD_BAD_ARG;
+    const md_attn_args args = with_head_strides(a_in);
+    const md_attn_args* a = &args;
     if (a->lddq % 4 || a->lddk % 4 || a->lddv % 4 || a->lddo % 8 || a->sdo % 8) return MD_BAD_ARG;
-    // one fused launch per (batch, head) for the training shapes; the split pair for longer sequences (res-512 mixer: 1024)
-    if (a->bwd_split < 0 || a->bwd_split > 5) return MD_BAD_ARG;
+    if (a->bwd_split < 0 || a->bwd_split > 5 || a->bwd_split == 1) return MD_BAD_ARG;
     const bool long_seq = a->Sq > 256 || a->Skv > 256;
-    if (a->bwd_split == 5 || (a->bwd_split == 0 && long_seq)) {      // the streaming pair (any size; the library's choice for long sequences)
+    if (a->bwd_split == 5 || (a->bwd_split == 0 && long_seq)) {
         if (a->hd == 64) launch_bwd_stream<64>(a, stream);
         else launch_bwd_stream<32>(a, stream);
         MD_LAUNCH_CHECK();
         return 0;
     }
-    if (a->bwd_split != 1) {
-        if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
-            MD_LAUNCH_CHECK();
-            return 0;
-        }
-        if (a->bwd_split != 0) return -1;      // a forced fused variant that does not cover this problem: nothing was launched
+    if (a->hd == 64 ? launch_bwd_fused<64>(a, a->bwd_split, stream) : launch_bwd_fused<32>(a, a->bwd_split, stream)) {
+        MD_LAUNCH_CHECK();
+        return 0;
     }
-    const int nwq = waves_for(a->Sq), nwk = waves_for(a->Skv);
-    dim3 gq((unsigned)((a->Sq + 32 * nwq - 1) / (32 * nwq)), (unsigned)a->H, (unsigned)a->B);
-    dim3 gk((unsigned)((a->Skv + 32 * nwk - 1) / (32 * nwk)), (unsigned)a->H, (unsigned)a->B);
-    if (a->hd == 64) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64 * nwq), 0, stream, *a);     // also writes delta
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * nwk), 0, stream, *a);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64 * nwq), 0, stream, *a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64 * nwk), 0, stream, *a);
-    }
-    MD_LAUNCH_CHECK();
-    return 0;
+    return -1;      // a forced fused variant that does not cover this problem: nothing was launched
 }

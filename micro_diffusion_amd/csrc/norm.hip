@@ -415,6 +415,134 @@ __global__ __launch_bounds__(256) void qkln_bwd_kernel(bf16* d, int64_t ldd, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Head-major forms (round 6): the normalised q / k go to a separate [seg][B, H, S, hd] buffer -- one contiguous [S, hd] block per
+// (sample, head), the tile an attention workgroup stages -- and dL/dy comes back in that layout.  A lane's 16-byte piece (8 columns)
+// lies inside one head, 8 lanes cover a head's 128 bytes (hd = 64): every store / load instruction moves whole 128-byte lines,
+// as the row-major form does.  Same arithmetic, same statistics buffer as the in-place kernels above.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HmMap {
+    int64_t S, H;
+    int hd_shift;      // hd = 1 << hd_shift (32 or 64)
+    __device__ __forceinline__ int64_t row_base(int64_t row) const {      // offset of (b, head 0, s, 0)
+        const int64_t b = row / S, s = row - b * S;
+        return (b * H * S + s) << hd_shift;
+    }
+    __device__ __forceinline__ int64_t col_off(int c) const {             // + offset of column c = h * hd + e
+        return ((int64_t)(c >> hd_shift) * S << hd_shift) + (c & ((1 << hd_shift) - 1));
+    }
+};
+template <int NCH>
+__device__ __forceinline__ void issue_row_hm(const bf16* base, const HmMap& m, int C, int lane, bf16x8 (&h)[NCH]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < C) h[j] = ld_bf16x8(base + m.col_off(c));
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[j][e] = (bf16)0.f;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void qkln_fwd_hm_kernel(const bf16* buf, int64_t rows, int64_t ld, int64_t col0, int C, int nseg,
+                                                          int64_t seg_stride, bf16* out, int64_t out_seg_stride, HmMap m,
+                                                          float* rstd_out, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t items = rows * nseg;                      // item vr = row * nseg + seg (see qkln_fwd_kernel)
+    const float invC = 1.f / (float)C;
+    auto at = [&](int64_t vr) { return buf + (vr / nseg) * ld + col0 + (vr % nseg) * seg_stride; };
+    bf16x8 nxt[NCH];
+    if (wave < items) issue_row<NCH>(at(wave), C, lane, nxt);
+    for (int64_t vr = wave; vr < items; vr += nwaves) {
+        float v[NCH][8];
+        unpack_row<NCH>(nxt, v);
+        if (vr + nwaves < items) issue_row<NCH>(at(vr + nwaves), C, lane, nxt);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];          // columns >= C were loaded as zeros
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane * 8 + j * 512;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[j][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        const int64_t row = vr / nseg, seg = vr % nseg;
+        if (lane == 0) rstd_out[seg * rows + row] = rstd;
+        bf16* orow = out + seg * out_seg_stride + m.row_base(row);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane * 8 + j * 512;
+            if (c < C) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf((v[j][e] - mean) * rstd);
+                st_bf16x8(orow + m.col_off(c), o);
+            }
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void qkln_bwd_hm_kernel(const bf16* dy, int64_t dy_seg_stride, const bf16* y, int64_t y_seg_stride,
+                                                          bf16* d, int64_t ldd, int64_t dcol0, int64_t dseg_stride, int64_t rows, int C,
+                                                          int nseg, HmMap m, const float* rstd_in) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t items = rows * nseg;
+    const float invC = 1.f / (float)C;
+    bf16x8 ng[NCH], ny[NCH];
+    float nrstd = 0.f;
+    auto issue = [&](int64_t vr) {
+        const int64_t row = vr / nseg, seg = vr % nseg, rb = m.row_base(row);
+        issue_row_hm<NCH>(dy + seg * dy_seg_stride + rb, m, C, lane, ng);
+        issue_row_hm<NCH>(y + seg * y_seg_stride + rb, m, C, lane, ny);
+        nrstd = rstd_in[seg * rows + row];
+    };
+    if (wave < items) issue(wave);
+    for (int64_t vr = wave; vr < items; vr += nwaves) {
+        bf16* dr = d + (vr / nseg) * ldd + dcol0 + (vr % nseg) * dseg_stride;
+        float g[NCH][8], xh[NCH][8];
+        unpack_row<NCH>(ng, g);
+        unpack_row<NCH>(ny, xh);
+        const float rstd = nrstd;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += g[j][e];
+                s2 += g[j][e] * xh[j][e];
+            }
+        if (vr + nwaves < items) issue(vr + nwaves);
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane * 8 + j * 512;
+            if (c < C) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(rstd * (g[j][e] - s1 - xh[j][e] * s2));
+                st_bf16x8(dr + c, o);
+            }
+        }
+    }
+}
+
 inline int ln_grid(int64_t rows) {
     int64_t g = (rows + 3) / 4;
     if (g > 4096) g = 4096;
@@ -497,6 +625,42 @@ extern "C" int md_qkln_bwd(void* d, int64_t ldd, int64_t dcol0, const void* y, i
         return MD_BAD_ARG;
 #define QKB(N) hipLaunchKernelGGL(qkln_bwd_kernel<N>, dim3(ln_grid(rows * nseg)), dim3(256), 0, stream, (bf16*)d, ldd, dcol0, \
                                   (const bf16*)y, ldy, ycol0, rows, (int)width, (int)nseg, dseg_stride, yseg_stride, rstd)
+    if (width <= 512) QKB(1); else if (width <= 1024) QKB(2); else QKB(4);
+#undef QKB
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+inline bool hm_ok(int64_t rows, int64_t width, int64_t S, int32_t hd) {
+    return S > 0 && rows % S == 0 && (hd == 32 || hd == 64) && width % hd == 0;
+}
+}  // namespace
+
+extern "C" int md_qkln_fwd_hm(const void* buf, int64_t rows, int64_t ld, int64_t col0, int64_t width, int32_t nseg, int64_t seg_stride,
+                              void* out, int64_t out_seg_stride, int64_t S, int32_t hd, float* rstd_out, float eps, hipStream_t stream) {
+    if (!buf || !out || !rstd_out || rows <= 0 || width <= 0 || width % 8 || width > 64 * 8 * MAXCH || ld % 8 || col0 % 8 || nseg < 1 ||
+        nseg > 4 || seg_stride % 8 || (nseg > 1 && (seg_stride < width || out_seg_stride < rows * width)) || out_seg_stride % 8 ||
+        !hm_ok(rows, width, S, hd))
+        return MD_BAD_ARG;
+    const HmMap m{S, width / hd, hd == 64 ? 6 : 5};
+#define QKF(N) hipLaunchKernelGGL(qkln_fwd_hm_kernel<N>, dim3(ln_grid(rows * nseg)), dim3(256), 0, stream, (const bf16*)buf, rows, ld, \
+                                  col0, (int)width, (int)nseg, seg_stride, (bf16*)out, out_seg_stride, m, rstd_out, eps)
+    if (width <= 512) QKF(1); else if (width <= 1024) QKF(2); else QKF(4);
+#undef QKF
+    MD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int md_qkln_bwd_hm(const void* dy, int64_t dy_seg_stride, const void* y, int64_t y_seg_stride, void* d, int64_t ldd,
+                              int64_t dcol0, int64_t dseg_stride, int64_t rows, int64_t width, int32_t nseg, int64_t S, int32_t hd,
+                              const float* rstd, hipStream_t stream) {
+    if (!dy || !y || !d || !rstd || rows <= 0 || width <= 0 || width % 8 || width > 64 * 8 * MAXCH || ldd % 8 || dcol0 % 8 ||
+        nseg < 1 || nseg > 4 || dseg_stride % 8 || dy_seg_stride % 8 || y_seg_stride % 8 || !hm_ok(rows, width, S, hd))
+        return MD_BAD_ARG;
+    const HmMap m{S, width / hd, hd == 64 ? 6 : 5};
+#define QKB(N) hipLaunchKernelGGL(qkln_bwd_hm_kernel<N>, dim3(ln_grid(rows * nseg)), dim3(256), 0, stream, (const bf16*)dy, dy_seg_stride, \
+                                  (const bf16*)y, y_seg_stride, (bf16*)d, ldd, dcol0, dseg_stride, rows, (int)width, (int)nseg, m, rstd)
     if (width <= 512) QKB(1); else if (width <= 1024) QKB(2); else QKB(4);
 #undef QKB
     MD_LAUNCH_CHECK();

@@ -110,6 +110,12 @@ class DiTEngine:
         self.kernel_profile = None         # bench.py: {class name: [(event0, event1, algorithmic bytes)]} for the bandwidth-bound kernels
         self.gemm_prefer = hip.GEMM_AUTO   # tests / A-B runs: a kernel to force wherever it accepts the problem (else the library's choice)
         self.attn_bwd_prefer = hip.ATTN_BWD_AUTO   # same for the attention backward (md_attn_args.bwd_split)
+        # Head-major q / k (round 6): QK-LayerNorm writes q / k as [B, H, S, hd] (md_qkln_fwd_hm), attention returns dq / dk in that
+        # layout and md_qkln_bwd_hm brings them back row-major.  Built, parity-tested and MEASURED NEUTRAL in the step (attention
+        # -10.5 ms, QK-LayerNorm +7 ms of a 2,311 ms profile; same-box A/B 2,658 vs 2,659 images/s at microbatch 1024, -0.6 % at 256:
+        # profiles/r6_head_major_qk.txt) -- v / o / dO / dv stay in packed rows unless the GEMM epilogues re-lay them.  Off by default
+        # (it costs 2/3 of a qkv buffer per block of tape); MD_QK_HEAD_MAJOR=1 or this attribute turns it on.
+        self.qk_head_major = os.environ.get("MD_QK_HEAD_MAJOR", "0") == "1"
         self.gemm_log = None               # tests: list that receives (variant actually requested, M, N, K, batch) per launch
         self.before_segment = None         # data parallelism: callable(bucket key) run before the first kernel that reads the bf16
         #                                    weights of a bucket ("rest", block names, "final_layer"): waits for their all-gather
@@ -205,6 +211,18 @@ class DiTEngine:
     def _qkln_bwd(self, dptr, ldd, doff, yptr, ldy, yoff, rows, width, rstd_ptr, nseg=1):
         self._prof("qk_layernorm", 6.0 * rows * width * nseg, lambda: hip.check(
             self.L.md_qkln_bwd(dptr, ldd, doff, yptr, ldy, yoff, rows, width, nseg, width, width, rstd_ptr, self._st()), "md_qkln_bwd"))
+
+    def _qkln_fwd_hm(self, ptr, rows, ld, off, width, out, S, rstd_ptr, nseg=1):
+        """As _qkln_fwd, the normalised values going head-major to out [nseg][B, H, S, hd]; the input stays as it is."""
+        self._prof("qk_layernorm", 4.0 * rows * width * nseg, lambda: hip.check(
+            self.L.md_qkln_fwd_hm(ptr, rows, ld, off, width, nseg, width, out.data_ptr(), rows * width, S, self.cfg.head_dim, rstd_ptr,
+                                  self.cfg.norm_eps, self._st()), "md_qkln_fwd_hm"))
+
+    def _qkln_bwd_hm(self, dy, y, dptr, ldd, doff, rows, width, S, rstd_ptr, nseg=1):
+        """dy, y: head-major [nseg][B, H, S, hd]; dL/dx goes row-major to dptr (segments `width` apart, as in _qkln_bwd)."""
+        self._prof("qk_layernorm", 6.0 * rows * width * nseg, lambda: hip.check(
+            self.L.md_qkln_bwd_hm(dy.data_ptr(), rows * width, y.data_ptr(), rows * width, dptr, ldd, doff, width, rows, width, nseg, S,
+                                  self.cfg.head_dim, rstd_ptr, self._st()), "md_qkln_bwd_hm"))
 
     def _attn_fwd(self, a):
         nb = 2.0 * a.hd * (2 * a.Sq + 2 * a.Skv) * a.B * a.H
@@ -447,11 +465,19 @@ class DiTEngine:
                    lambda: hip.check(self.L.md_ln_bwd(byref(a), byref(b), self._st()), "md_ln_bwd"))
 
     def attn_args(self, q, k, v, o, lse, B, H, Sq, Skv, ldq, ldk, ldv, hid, *, do=None, dq=None, dk=None, dv=None,
-                  delta=None, lddq=0, lddk=0, lddv=0):
+                  delta=None, lddq=0, lddk=0, lddv=0, hm_qk=False):
+        """hm_qk: q, k (and dq, dk) are head-major [B, H, S, hd] buffers (ldq / ldk / lddq / lddk are ignored)."""
         hd = self.cfg.head_dim
-        return hip.AttnArgs(q, k, v, _p(o), _p(lse), _p(do), dq, dk, dv, _p(delta), B, H, Sq, Skv, ldq, ldk, ldv, hid,
-                            Sq * ldq, Skv * ldk, Skv * ldv, Sq * hid, lddq, lddk, lddv, hid, Sq * lddq, Skv * lddk,
-                            Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd, 0)
+        a = hip.AttnArgs(q, k, v, _p(o), _p(lse), _p(do), dq, dk, dv, _p(delta), B, H, Sq, Skv, ldq, ldk, ldv, hid,
+                         Sq * ldq, Skv * ldk, Skv * ldv, Sq * hid, lddq, lddk, lddv, hid, Sq * lddq, Skv * lddk,
+                         Skv * lddv, Sq * hid, 1.0 / math.sqrt(hd), hd, 0)
+        if hm_qk:
+            a.ldq = a.ldk = a.lddq = a.lddk = hd
+            a.sq = a.sdq = H * Sq * hd
+            a.sk = a.sdk = H * Skv * hd
+            a.hsq = a.hsdq = Sq * hd
+            a.hsk = a.hsdk = Skv * hd
+        return a
 
     def _attn_bwd(self, a):
         self._prof("attention", 2.0 * a.hd * (4 * a.Sq + 4 * a.Skv) * a.B * a.H, lambda: self._attn_bwd_launch(a))
@@ -473,11 +499,18 @@ class DiTEngine:
         qkv = self.empty(M, 3 * hid)
         self.lin_fwd(xin, pre + ".qkv", qkv, M, 3 * hid, dim)
         rq = self.empty(2, M, dtype=F32)
-        self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq.data_ptr(), nseg=2)
         o = self.empty(M, hid)
         lse = self.empty(B, heads, S, dtype=F32)
-        a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
-                           3 * hid, 3 * hid, 3 * hid, hid)
+        if self.qk_head_major:
+            t.qk = self.empty(2, M, hid)          # normalised q, k: [2][B, H, S, hd]; qkv keeps the raw q / k (dead) and v
+            self._qkln_fwd_hm(qkv.data_ptr(), M, 3 * hid, 0, hid, t.qk, S, rq.data_ptr(), nseg=2)
+            a = self.attn_args(t.qk.data_ptr(), t.qk.data_ptr() + 2 * M * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
+                               0, 0, 3 * hid, hid, hm_qk=True)
+        else:
+            t.qk = None
+            self._qkln_fwd(qkv.data_ptr(), M, 3 * hid, 0, hid, rq.data_ptr(), nseg=2)
+            a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, o, lse, B, heads, S, S,
+                               3 * hid, 3 * hid, 3 * hid, hid)
         self._attn_fwd(a)
         t.qkv, t.rq, t.o, t.lse = qkv, rq, o, lse
         return o
@@ -488,11 +521,19 @@ class DiTEngine:
         dqkv = self.empty(M, 3 * hid)
         delta = self.empty(B, heads, S, dtype=F32)
         qkv = t.qkv
-        a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, t.o, t.lse, B, heads, S, S,
-                           3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
-                           dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
-        self._attn_bwd(a)
-        self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq.data_ptr(), nseg=2)
+        if t.qk is not None:
+            dqk = self.empty(2, M, hid)           # dL/d(normalised q, k), head-major like t.qk
+            a = self.attn_args(t.qk.data_ptr(), t.qk.data_ptr() + 2 * M * hid, qkv.data_ptr() + 4 * hid, t.o, t.lse, B, heads, S, S,
+                               0, 0, 3 * hid, hid, do=do, dq=dqk.data_ptr(), dk=dqk.data_ptr() + 2 * M * hid,
+                               dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddv=3 * hid, hm_qk=True)
+            self._attn_bwd(a)
+            self._qkln_bwd_hm(dqk, t.qk, dqkv.data_ptr(), 3 * hid, 0, M, hid, S, t.rq.data_ptr(), nseg=2)
+        else:
+            a = self.attn_args(qkv.data_ptr(), qkv.data_ptr() + 2 * hid, qkv.data_ptr() + 4 * hid, t.o, t.lse, B, heads, S, S,
+                               3 * hid, 3 * hid, 3 * hid, hid, do=do, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + 2 * hid,
+                               dv=dqkv.data_ptr() + 4 * hid, delta=delta, lddq=3 * hid, lddk=3 * hid, lddv=3 * hid)
+            self._attn_bwd(a)
+            self._qkln_bwd(dqkv.data_ptr(), 3 * hid, 0, qkv.data_ptr(), 3 * hid, 0, M, hid, t.rq.data_ptr(), nseg=2)
         self.lin_wgrad(dqkv, xin, pre + ".qkv", M, 3 * hid, dim, defer=defer)
         dxin = self.empty(M, dim)
         self.lin_dgrad(dqkv, pre + ".qkv", dxin, M, 3 * hid, dim)
@@ -530,18 +571,27 @@ class DiTEngine:
         t.xn2 = self.empty(M, d)
         t.st2 = self.empty(2, M, dtype=F32)
         self.ln_fwd(self.ln_args(x1, n + ".norm2", t.xn2, M, d, mean=t.st2[0], rstd=t.st2[1]))
-        t.q2 = self.empty(M, hx)
+        t.o2 = self.empty(M, hx)
+        # head-major: the raw q is dead once md_qkln_fwd_hm has read it -- it is staged in the buffer attention then writes o into
+        t.q2 = t.o2 if self.qk_head_major else self.empty(M, hx)
         self.lin_fwd(t.xn2, n + ".cross_attn.q_linear", t.q2, M, hx, d)
         t.kv = self.empty(Mc, 2 * hx)
         self.lin_fwd(ycond, n + ".cross_attn.kv_linear", t.kv, Mc, 2 * hx, d)
         t.rq2 = self.empty(M, dtype=F32)
         t.rk2 = self.empty(Mc, dtype=F32)
-        self._qkln_fwd(t.q2.data_ptr(), M, hx, 0, hx, t.rq2.data_ptr())
-        self._qkln_fwd(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.rk2.data_ptr())
-        t.o2 = self.empty(M, hx)
         t.lse2 = self.empty(B, bp.xheads, S, dtype=F32)
-        ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc,
-                            hx, 2 * hx, 2 * hx, hx)
+        if self.qk_head_major:
+            t.q2n, t.k2n = self.empty(M, hx), self.empty(Mc, hx)        # normalised q [B, H, S, hd], k [B, H, Lc, hd]
+            self._qkln_fwd_hm(t.q2.data_ptr(), M, hx, 0, hx, t.q2n, S, t.rq2.data_ptr())
+            self._qkln_fwd_hm(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.k2n, Lc, t.rk2.data_ptr())
+            ax = self.attn_args(t.q2n.data_ptr(), t.k2n.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc,
+                                0, 0, 2 * hx, hx, hm_qk=True)
+        else:
+            t.q2n = t.k2n = None
+            self._qkln_fwd(t.q2.data_ptr(), M, hx, 0, hx, t.rq2.data_ptr())
+            self._qkln_fwd(t.kv.data_ptr(), Mc, 2 * hx, 0, hx, t.rk2.data_ptr())
+            ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc,
+                                hx, 2 * hx, 2 * hx, hx)
         self._attn_fwd(ax)
         x2 = self.empty(M, d)
         self.lin_fwd(t.o2, n + ".cross_attn.proj", x2, M, d, hx, mode=hip.EPI_RESIDUAL, res=x1)
@@ -681,12 +731,21 @@ class DiTEngine:
         dq2 = self.empty(M, hx)
         dkv = self.empty(Mc, 2 * hx) if kvgroup is None else kvgroup["buf"][len(kvgroup["w"])]
         delta = self.empty(B, bp.xheads, S, dtype=F32)
-        ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, hx,
-                            2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
-                            delta=delta, lddq=hx, lddk=2 * hx, lddv=2 * hx)
-        self._attn_bwd(ax)
-        self._qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr())
-        self._qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr())
+        if t.q2n is not None:
+            dq2n, dk2n = self.empty(M, hx), self.empty(Mc, hx)          # head-major like t.q2n / t.k2n
+            ax = self.attn_args(t.q2n.data_ptr(), t.k2n.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, 0,
+                                0, 2 * hx, hx, do=do2, dq=dq2n.data_ptr(), dk=dk2n.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
+                                delta=delta, lddv=2 * hx, hm_qk=True)
+            self._attn_bwd(ax)
+            self._qkln_bwd_hm(dq2n, t.q2n, dq2.data_ptr(), hx, 0, M, hx, S, t.rq2.data_ptr())
+            self._qkln_bwd_hm(dk2n, t.k2n, dkv.data_ptr(), 2 * hx, 0, Mc, hx, Lc, t.rk2.data_ptr())
+        else:
+            ax = self.attn_args(t.q2.data_ptr(), t.kv.data_ptr(), t.kv.data_ptr() + 2 * hx, t.o2, t.lse2, B, bp.xheads, S, Lc, hx,
+                                2 * hx, 2 * hx, hx, do=do2, dq=dq2.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + 2 * hx,
+                                delta=delta, lddq=hx, lddk=2 * hx, lddv=2 * hx)
+            self._attn_bwd(ax)
+            self._qkln_bwd(dq2.data_ptr(), hx, 0, t.q2.data_ptr(), hx, 0, M, hx, t.rq2.data_ptr())
+            self._qkln_bwd(dkv.data_ptr(), 2 * hx, 0, t.kv.data_ptr(), 2 * hx, 0, Mc, hx, t.rk2.data_ptr())
         self.lin_wgrad(dq2, t.xn2, n + ".cross_attn.q_linear", M, hx, d, defer=True)
         self.lin_wgrad(dkv, ycond, n + ".cross_attn.kv_linear", Mc, 2 * hx, d)
         # d(ycond) accumulates in fp32 over all blocks that attend to these caption tokens: per block (split-K slices + a

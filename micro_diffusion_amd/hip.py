@@ -28,7 +28,7 @@ EPI_STORE_BF16, EPI_RESIDUAL, EPI_STORE_F32, EPI_ACCUM_F32, EPI_ATOMIC_F32, EPI_
 GEMM_AUTO, GEMM_REG128, GEMM_DMA128, GEMM_PACED256, GEMM_PP256, GEMM_W4 = 0, 1, 2, 3, 4, 5
 GEMM_VARIANT_NAMES = {"auto": 0, "reg128": 1, "dma128": 2, "paced256": 3, "pp256": 4, "w4": 5}
 # md_attn_args.bwd_split: backward kernel selector (0 = the library's rule; the others force a kernel: tests, A/B runs)
-ATTN_BWD_AUTO, ATTN_BWD_PAIR, ATTN_BWD_FUSED_1PHASE, ATTN_BWD_FUSED_2PHASE, ATTN_BWD_FUSED_2PHASE_SPLIT, ATTN_BWD_STREAM_PAIR = 0, 1, 2, 3, 4, 5
+ATTN_BWD_AUTO, ATTN_BWD_FUSED_1PHASE, ATTN_BWD_FUSED_2PHASE, ATTN_BWD_FUSED_2PHASE_SPLIT, ATTN_BWD_STREAM_PAIR = 0, 2, 3, 4, 5   # (1: removed)
 
 
 def _sources():
@@ -122,7 +122,7 @@ class GemmArgs(Structure):
 
 
 _lib = None
-ABI_VERSION = 5        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
+ABI_VERSION = 6        # MD_ABI_VERSION of include/microdit_hip.h this binding was written against
 
 
 def lib() -> ctypes.CDLL:
@@ -192,7 +192,9 @@ class AttnArgs(Structure):
                 ("sq", c_int64), ("sk", c_int64), ("sv", c_int64), ("so", c_int64),
                 ("lddq", c_int64), ("lddk", c_int64), ("lddv", c_int64), ("lddo", c_int64),
                 ("sdq", c_int64), ("sdk", c_int64), ("sdv", c_int64), ("sdo", c_int64),
-                ("scale", c_float), ("hd", c_int32), ("bwd_split", c_int32)]
+                ("scale", c_float), ("hd", c_int32), ("bwd_split", c_int32),
+                ("hsq", c_int64), ("hsk", c_int64), ("hsv", c_int64), ("hso", c_int64),      # ABI 6: per-tensor head strides
+                ("hsdq", c_int64), ("hsdk", c_int64), ("hsdv", c_int64), ("hsdo", c_int64)]  # (0 = hd: heads packed in the row)
 
 
 class AdamWArgs(Structure):
@@ -213,6 +215,8 @@ _sig("md_ln_fwd", POINTER(LnArgs), P)
 _sig("md_ln_bwd", POINTER(LnArgs), POINTER(LnBwdArgs), P)
 _sig("md_qkln_fwd", P, I64, I64, I64, I64, I32, I64, P, F32, P)
 _sig("md_qkln_bwd", P, I64, I64, P, I64, I64, I64, I64, I32, I64, I64, P, P)
+_sig("md_qkln_fwd_hm", P, I64, I64, I64, I64, I32, I64, P, I64, I64, I32, P, F32, P)
+_sig("md_qkln_bwd_hm", P, I64, P, I64, P, I64, I64, I64, I64, I64, I32, I64, I32, P, P)
 _sig("md_attn_fwd", POINTER(AttnArgs), P)
 _sig("md_attn_bwd", POINTER(AttnArgs), P)
 _sig("md_swiglu_fwd", P, I64, P, I64, I64, I64, P)

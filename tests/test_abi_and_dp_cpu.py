@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
-    assert lib.md_abi_version() == 5 == hip.ABI_VERSION
-    assert re.search(r"#define MD_ABI_VERSION 5\b", header)
+    assert lib.md_abi_version() == 6 == hip.ABI_VERSION
+    assert re.search(r"#define MD_ABI_VERSION 6\b", header)
 
 
 def test_product_never_imports_oracle():

@@ -117,6 +117,45 @@ def test_qkln(hip, width):
     close(dwork[:, :2 * width], ref_in.grad[:, :2 * width], rel=3e-2, what="qkln bwd")
 
 
+@pytest.mark.parametrize("width,hd,S,B", [(1024, 64, 64, 5), (768, 64, 256, 2), (1024, 64, 77, 3), (128, 32, 40, 4), (2048, 64, 64, 2)])
+def test_qkln_head_major(hip, width, hd, S, B):
+    """md_qkln_fwd_hm / md_qkln_bwd_hm against the in-place row-major kernels: the SAME bits, re-laid -- normalised q / k as
+    [seg][B, H, S, hd], statistics identical, the input untouched; the backward reads dL/dy and y head-major and writes dL/dx into the
+    packed rows, leaving the third (v) column block alone."""
+    torch.manual_seed(width + S)
+    L, st = hip.lib(), hip.stream_ptr()
+    rows, ld, H = B * S, 3 * width, width // hd
+    buf = bf(torch.randn(rows, ld, device=DEV) * 2 + 0.5)
+    work, rstd = buf.clone(), torch.empty(2, rows, device=DEV)
+    hip.check(L.md_qkln_fwd(work.data_ptr(), rows, ld, 0, width, 2, width, rstd.data_ptr(), 1e-6, st), "qkln")
+    src, out, rstd2 = buf.clone(), torch.zeros(2, B, H, S, hd, device=DEV, dtype=torch.bfloat16), torch.empty(2, rows, device=DEV)
+    hip.check(L.md_qkln_fwd_hm(src.data_ptr(), rows, ld, 0, width, 2, width, out.data_ptr(), rows * width, S, hd, rstd2.data_ptr(),
+                               1e-6, st), "qkln hm")
+    torch.cuda.synchronize()
+    assert torch.equal(src, buf), "the head-major forward must not write its input"
+    assert torch.equal(rstd2, rstd)
+
+    def to_hm(x):          # [rows, width] -> [B, H, S, hd]
+        return x.reshape(B, S, H, hd).permute(0, 2, 1, 3).contiguous()
+
+    assert torch.equal(out[0], to_hm(work[:, :width])) and torch.equal(out[1], to_hm(work[:, width:2 * width]))
+    d = bf(torch.randn(rows, ld, device=DEV))
+    want = d.clone()
+    hip.check(L.md_qkln_bwd(want.data_ptr(), ld, 0, work.data_ptr(), ld, 0, rows, width, 2, width, width, rstd.data_ptr(), st), "b")
+    dy = torch.stack([to_hm(d[:, :width]), to_hm(d[:, width:2 * width])])
+    got = d.clone()
+    got[:, :2 * width] = 7.0                     # must be overwritten, not accumulated into
+    hip.check(L.md_qkln_bwd_hm(dy.data_ptr(), rows * width, out.data_ptr(), rows * width, got.data_ptr(), ld, 0, width, rows, width, 2,
+                               S, hd, rstd.data_ptr(), st), "b hm")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # refusals: rows not a multiple of S, head_dim not 32 / 64
+    assert L.md_qkln_fwd_hm(src.data_ptr(), rows, ld, 0, width, 2, width, out.data_ptr(), rows * width, S + 1, hd, rstd2.data_ptr(),
+                            1e-6, st) == -1
+    assert L.md_qkln_fwd_hm(src.data_ptr(), rows, ld, 0, width, 2, width, out.data_ptr(), rows * width, S, 48, rstd2.data_ptr(),
+                            1e-6, st) == -1
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, H, hd):
     B, Sq, _ = q.shape
@@ -135,18 +174,21 @@ def _attn_ref(q, k, v, H, hd):
                                                     (2, 3, 1024, 77, 64, False),      # res-512 mixer cross-attention: 4 query blocks x 1 key block
                                                     (1, 2, 600, 300, 64, False),      # ragged 3 x 2 block grid (idle workgroups in a round)
                                                     (1, 2, 300, 700, 32, False)])     # more key blocks than query blocks, head_dim 32
-@pytest.mark.parametrize("bwd_split", [0, 1, 2, 3, 4, 5])
-def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
+@pytest.mark.parametrize("bwd_split", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("layout", ["packed", "head_major_qk"])
+def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split, layout):
     """bwd_split 0: the library's choice (ONE fused backward launch per (batch, head) when Sq, Skv <= 256; longer sequences --
-    the res-512 mixer, 1024 tokens -- on the streaming pair); 1: the
-    dQ + dK/dV kernel pair; 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V in LDS together; Sq, Skv <= 256
-    only) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4); any length) form;
-    5: the streaming pair (128-row chunks with register prefetch, up to 8 waves per workgroup; the library's choice for long sequences) --
-    a forced form that does not cover the problem must refuse it (-1) and launch nothing.  All against torch fp32 autograd of
-    the same bf16 inputs."""
+    the res-512 mixer, 1024 tokens -- on the streaming pair); 2 / 3 / 4: the fused backward forced to its single-phase (Q, dO, K, V
+    in LDS together) or two-phase (half the LDS image; dK / dV in two passes for the 256-row buckets (3) or always (4)) form, all
+    three for Sq, Skv <= 256 only; 5: the streaming pair (128-row chunks with register prefetch, up to 8 waves per workgroup) --
+    a forced form that does not cover the problem must refuse it (-1) and launch nothing.
+    layout "head_major_qk": q, k, dq, dk as [B, H, S, hd] (md_attn_args.hsq / hsk / hsdq / hsdk -- what md_qkln_fwd_hm writes and
+    md_qkln_bwd_hm reads), v / o / dO / dv in the packed rows.  All against torch fp32 autograd of the same bf16 inputs
+    (utils.py:116-132,177-193)."""
     torch.manual_seed(B * H + Sq + Skv + hd)
     L, st = hip.lib(), hip.stream_ptr()
     hid = H * hd
+    hm = layout == "head_major_qk"
     if packed:   # self-attention: [B, S, 3, H, hd]
         qkv = bf(torch.randn(B, Sq, 3 * hid, device=DEV))
         q, k, v = qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:]
@@ -175,15 +217,31 @@ def test_attention(hip, B, H, Sq, Skv, hd, packed, bwd_split):
                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Sq, Skv,
                      ldq, ldk, ldv, hid, sq, sk, sv, Sq * hid, lddq, lddk, lddv, hid, sdq, sdk, sdv, Sq * hid,
                      1.0 / math.sqrt(hd), hd, bwd_split)
+    if hm:       # the same values, q / k re-laid as [B, H, S, hd]; dq / dk come back in that layout
+        q_hm = q.reshape(B, Sq, H, hd).permute(0, 2, 1, 3).contiguous()
+        k_hm = k.reshape(B, Skv, H, hd).permute(0, 2, 1, 3).contiguous()
+        dq_hm, dk_hm = torch.zeros_like(q_hm), torch.zeros_like(k_hm)
+        a.q, a.k, a.dq, a.dk = q_hm.data_ptr(), k_hm.data_ptr(), dq_hm.data_ptr(), dk_hm.data_ptr()
+        a.ldq = a.ldk = a.lddq = a.lddk = hd
+        a.sq = a.sdq = H * Sq * hd
+        a.sk = a.sdk = H * Skv * hd
+        a.hsq = a.hsdq = Sq * hd
+        a.hsk = a.hsdk = Skv * hd
     hip.check(L.md_attn_fwd(byref(a), st), "attn fwd")
-    covered = bwd_split != 2 or max(Sq, Skv) <= 256
+    covered = bwd_split in (0, 5) or max(Sq, Skv) <= 256
     rc = L.md_attn_bwd(byref(a), st)
     if not covered:
         torch.cuda.synchronize()
         assert rc == -1, f"forced backward form {bwd_split} must refuse Sq={Sq} Skv={Skv} (rc {rc})"
-        assert float(dq.abs().max()) == 0.0 and float(dk.abs().max()) == 0.0, "a refused launch must not write"
+        got_q, got_k = (dq_hm, dk_hm) if hm else (dq, dk)
+        assert float(got_q.abs().max()) == 0.0 and float(got_k.abs().max()) == 0.0, "a refused launch must not write"
         return
     hip.check(rc, "attn bwd")
+    a.bwd_split = 1                                   # the round-4 kernel pair was removed with ABI 6: not a valid selector any more
+    assert L.md_attn_bwd(byref(a), st) == -1
+    if hm:
+        dq = dq_hm.permute(0, 2, 1, 3).reshape(B, Sq, hid)
+        dk = dk_hm.permute(0, 2, 1, 3).reshape(B, Skv, hid)
     qr = q.float().clone().requires_grad_(True)
     kr = k.float().clone().requires_grad_(True)
     vr = v.float().clone().requires_grad_(True)
