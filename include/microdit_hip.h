@@ -140,7 +140,10 @@ enum md_gemm_variant {
 };
 
 int md_gemm_bf16(const md_gemm_args* args, hipStream_t stream);
-/* out[b] (+)= sum over the ksplit dense fp32 [M, N] slices a split-K md_gemm_bf16 left in ws (deterministic). */
+/* out[b] (+)= sum over the ksplit dense fp32 [M, N] slices a split-K md_gemm_bf16 left in ws (deterministic).
+ * accumulate: 0 = store fp32, 1 = add to the fp32 out, 2 (ABI 6) = round the sum to bf16 and STORE it: out is then a bf16 matrix
+ * (ldo / sOut in bf16 elements) -- the gradient-exchange buffer of a step that has one microbatch (configs/res_256_pretrain.yaml:24,111:
+ * a rank of the 8-GPU run), which needs no fp32 accumulator pass.  Same for the flat form. */
 int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo, int64_t sOut, int32_t ksplit,
                      int32_t batch, int32_t accumulate, hipStream_t stream);
 

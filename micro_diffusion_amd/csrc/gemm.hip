@@ -563,6 +563,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
             const float4 v = nt_ld4(src + (int64_t)s * slice);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+        if (accumulate == 2) {           // bf16 store (out is a bf16 matrix: the gradient-exchange buffer of a one-microbatch step)
+            bf16x4 o;
+            o[0] = f2bf(acc.x); o[1] = f2bf(acc.y); o[2] = f2bf(acc.z); o[3] = f2bf(acc.w);
+            st_bf16x4(reinterpret_cast<bf16*>(out) + b * sOut + m * ldo + c, o);
+            continue;
+        }
         float* dst = out + b * sOut + m * ldo + c;
         if (accumulate) {
             const float4 o = *reinterpret_cast<const float4*>(dst);
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
 
 extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t N, int64_t ldo, int64_t sOut, int32_t ksplit,
                                 int32_t batch, int32_t accumulate, hipStream_t stream) {
-    if (!ws || !out || M <= 0 || N <= 0 || N % 4 || ldo % 4 || ksplit <= 0 || batch <= 0) return MD_BAD_ARG;
+    if (!ws || !out || M <= 0 || N <= 0 || N % 4 || ldo % 4 || ksplit <= 0 || batch <= 0 || accumulate < 0 || accumulate > 2) return MD_BAD_ARG;
     int64_t grid = (M * (N / 4) * batch + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, M, N, ldo, sOut, ksplit, batch,
@@ -587,7 +593,7 @@ extern "C" int md_splitk_reduce(const float* ws, float* out, int64_t M, int64_t 
 
 extern "C" int md_splitk_reduce_flat(const float* ws, float* out, int64_t n, int64_t slice_stride, int32_t ksplit, int32_t accumulate,
                                      hipStream_t stream) {
-    if (!ws || !out || n <= 0 || n % 4 || slice_stride < n || slice_stride % 4 || ksplit <= 0) return MD_BAD_ARG;
+    if (!ws || !out || n <= 0 || n % 4 || slice_stride < n || slice_stride % 4 || ksplit <= 0 || accumulate < 0 || accumulate > 2) return MD_BAD_ARG;
     int64_t grid = (n / 4 + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, out, (int64_t)1, n, n, (int64_t)0, ksplit, 1,
@@ -620,6 +626,9 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (a->ksplit > 1 && !(a->mode == MD_EPI_ATOMIC_F32 || (a->mode == MD_EPI_STORE_F32 && a->sSplit > 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
+    // dact_cached: C2 of the forward (STORE_BF16) holds gelu'(h) in place of h and the DACT launch multiplies by aux as it is -- both
+    // sides only with the erf-GELU, the forward only with a C2 to write (every kernel family checks the same thing here, once)
+    if (a->dact_cached && (a->act != MD_ACT_GELU_ERF || !(a->mode == MD_EPI_DACT || (a->mode == MD_EPI_STORE_BF16 && a->C2)))) return MD_BAD_ARG;
     // Kernel choice.  a->variant forces one (parity tests drive every kernel on the real shapes; A/B runs); AUTO applies the
     // rules measured on MI355X in the XL/2 shape mix (profiles/r2_gemm_variants.txt):
     //  * PP256 (persistent ping-pong) whenever it is eligible and the launch has enough tiles to fill the chip;

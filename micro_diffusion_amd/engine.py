@@ -144,6 +144,11 @@ class DiTEngine:
         self.batch_adaln = True     # the modulation of ALL blocks from one GEMM per forward (A/B: False = one small GEMM per block)
         self._adaln = self._adaln_region()
         self.gemm_tail_mode = int(os.environ.get("MD_GEMM_TAIL", "0"))   # md_gemm_args.tail_mode: 0 = the library decides, 1 = never, 2 = always (A/B)
+        # One-microbatch steps of the data-parallel Trainer (a rank of the 8-GPU run: configs/res_256_pretrain.yaml:24,111): weight
+        # gradients whose fp32 accumulator lies in [g_lo, g_hi) are STORED as bf16 at gbf + (addr - g_lo) / 2 -- the exchange buffer of
+        # GradSync -- by the split-K reduction (or the GEMM epilogue when nothing is split): no read-modify-write of the fp32
+        # accumulator, no cast + clear pass afterwards.  (g_lo, g_hi, gbf address, {fp32 address: elements stored} of this step)
+        self.wgrad_bf16 = None
         self.cu_limit_fn = None     # data parallelism: callable() -> CUs the persistent GEMM may occupy right now (0 = all): the
         #                             Trainer leaves the CUs of RCCL's channels free while a collective is in flight
 
@@ -340,7 +345,14 @@ class DiTEngine:
         via_ws = ks != 1
         if ks == -1:                      # enough tiles without splitting: one slice through the workspace on pp256
             ks, via_ws = 1, self.single_slice_ws
+        bf_ptr = self._wgrad_bf16_target(out_ptr, M * N * batch if sOut in (0, M * N) and ldo == N else None) if accumulate else None
+        if bf_ptr is not None and not via_ws and ldo % 8:
+            via_ws = True                 # a bf16 row pitch the GEMM epilogue cannot store (16-byte pieces): one slice + the reduction
         if not via_ws:
+            if bf_ptr is not None:
+                self._gemm(C=bf_ptr, M=M, N=N, K=K, ldc=ldo, sC=sOut, batch=batch, ksplit=1, mode=hip.EPI_STORE_BF16, act=0, alpha=1.0,
+                           **operands)
+                return
             self._gemm(C=out_ptr, M=M, N=N, K=K, ldc=ldo, sC=sOut, batch=batch, ksplit=1,
                        mode=hip.EPI_ACCUM_F32 if accumulate else hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
             return
@@ -348,9 +360,25 @@ class DiTEngine:
             operands = dict(operands, variant=hip.GEMM_PP256)
         self._gemm(C=self.ws.data_ptr(), M=M, N=N, K=K, ldc=N, sC=ks * M * N, sSplit=M * N, batch=batch, ksplit=ks,
                    mode=hip.EPI_STORE_F32, act=0, alpha=1.0, **operands)
+        if bf_ptr is not None:
+            self._prof("splitk_reduce", M * N * batch * (4.0 * ks + 2), lambda: hip.check(
+                self.L.md_splitk_reduce(self.ws.data_ptr(), bf_ptr, M, N, ldo, sOut, ks, batch, 2, self._st()), "md_splitk_reduce"))
+            return
         self._prof("splitk_reduce", 4.0 * M * N * batch * (ks + (2 if accumulate else 1)), lambda: hip.check(
             self.L.md_splitk_reduce(self.ws.data_ptr(), out_ptr, M, N, ldo, sOut, ks, batch, 1 if accumulate else 0, self._st()),
             "md_splitk_reduce"))
+
+    def _wgrad_bf16_target(self, out_ptr, numel):
+        """Address in the bf16 exchange buffer a weight gradient of this step is stored at, or None (not a one-microbatch step, the
+        output is not a gradient accumulator, or the tensor is not dense).  A second gradient for the same tensor within one backward
+        would have to be ADDED: no layer of the model does that; it raises instead of silently dropping the first."""
+        t = self.wgrad_bf16
+        if t is None or numel is None or not (t["g_lo"] <= out_ptr < t["g_hi"]):
+            return None
+        if out_ptr in t["written"]:
+            raise RuntimeError("two weight gradients for one tensor in a one-microbatch step: the bf16 store path cannot accumulate")
+        t["written"][out_ptr] = numel          # fp32 address -> elements stored from there (may span adjacent tensors: [w1; w2])
+        return t["gbf"] + (out_ptr - t["g_lo"]) // 2
 
     def lin_wgrad(self, dy, x, wname, M, N, K, *, lddy=None, ldx=None, dyoff=0, xoff=0, bias_from=None, defer=False):
         """grad W[N,K] += dy[M,N]^T @ x[M,K]  (both operands K-strided; split-K over the token dimension);
@@ -427,8 +455,17 @@ class DiTEngine:
                 runs.append(cur)
                 cur = [g["out"], g["out"] + 4 * g["M"] * g["N"]]
         runs.append(cur)
+        bf = [self._wgrad_bf16_target(g["out"], g["M"] * g["N"]) for g in grp]
+        to_bf16 = all(b is not None for b in bf)
+        assert to_bf16 or not any(b is not None for b in bf)        # a group lies in the gradient buffer as a whole, or not at all
         for lo, hi in runs:
             n = (hi - lo) // 4
+            if to_bf16:
+                t = self.wgrad_bf16
+                dst = t["gbf"] + (lo - t["g_lo"]) // 2
+                self._prof("splitk_reduce", n * (4.0 * ks + 2), lambda lo=lo, n=n, dst=dst: hip.check(
+                    self.L.md_splitk_reduce_flat(self.ws.data_ptr() + (lo - base), dst, n, span_el, ks, 2, self._st()), "md_splitk_reduce_flat"))
+                continue
             self._prof("splitk_reduce", 4.0 * n * (ks + 2), lambda lo=lo, n=n: hip.check(
                 self.L.md_splitk_reduce_flat(self.ws.data_ptr() + (lo - base), lo, n, span_el, ks, 1, self._st()), "md_splitk_reduce_flat"))
 

@@ -199,6 +199,67 @@ def test_rccl_exchange_path_on_one_rank(hip, exchange, dp_mode, transport):
     assert bad <= tol_frac, f"{bad:.2e} of the parameters differ by more than 1e-5 after one step"
 
 
+def _one_microbatch_main(port, out_path):
+    """One rank over RCCL, sharded exchange, the rank's whole batch as ONE microbatch (a rank of the 8-GPU run: res_256_pretrain.yaml:24,111):
+    the step with weight gradients stored straight into the bf16 exchange buffer against the same step through the fp32 accumulators."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from micro_diffusion_amd.trainer import Trainer
+        res = {}
+        for store in (False, True):
+            model, opt, tr, part = _build((0, BATCH), "bf16", BATCH)
+            tr = Trainer(model, opt, tr.schedule, clip_norm=0.25, microbatch_size=BATCH, exchange="bf16", single_rank_exchange=True,
+                         dp_mode="sharded")
+            tr.sync.store_bf16 = store
+            loss = tr.train_step(part)
+            torch.cuda.synchronize()
+            f = model.dit.flat_buffers()
+            res[store] = {"gbf": tr.sync.gbf.detach().float().cpu(), "stored": tr.sync.last_stored, "loss": float(loss),
+                          "gnorm": float(opt.grad_norm().item()), "g_zero": bool((f["g"] == 0).all().item())}
+            tr.sync.wait_gather()
+            torch.cuda.synchronize()
+            res[store]["p"] = f["p"].detach().cpu()
+            res[store]["n_matrix"] = sum(1 for n, v in f["P"].items() if v.dim() >= 2)
+            loss2 = tr.train_step(part)            # a second step on the same buffers (nothing stale in gbf, accumulators still clean)
+            torch.cuda.synchronize()
+            res[store]["loss2"] = float(loss2)
+            res[store]["g_zero2"] = bool((f["g"] == 0).all().item())
+            del model, opt, tr
+            torch.cuda.empty_cache()
+        torch.save(res, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_microbatch_step_stores_bf16_gradients(hip):
+    """DiTEngine.wgrad_bf16 / GradSync.begin_backward: with one microbatch per step the split-K reduction (or the GEMM epilogue) writes
+    bf16 weight gradients into the exchange buffer; the fp32 accumulators stay untouched (zero), the cast + clear pass runs only for
+    what was not stored.  The staged gradient must equal the accumulate-then-cast one up to the bf16 rounding of a differently ordered
+    fp32 sum, and the updated weights must agree."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r.pt")
+        ctx = mp.get_context("spawn")
+        proc = ctx.Process(target=_one_microbatch_main, args=(_free_port(), out))
+        proc.start()
+        proc.join(600)
+        assert proc.exitcode == 0, f"process failed: {proc.exitcode}"
+        r = torch.load(out)
+    a, b = r[False], r[True]
+    assert a["stored"] == 0 and b["stored"] >= 0.8 * b["n_matrix"], (a["stored"], b["stored"], b["n_matrix"])
+    assert a["g_zero"] and b["g_zero"] and a["g_zero2"] and b["g_zero2"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])               # the forward is the same
+    d = (a["gbf"] - b["gbf"]).abs()
+    scale = a["gbf"].abs().clamp_min(1e-12)
+    assert float((d > 0.0079 * scale).float().mean()) <= 1e-4, "more than 1e-4 of the staged gradient differs by more than one bf16 ulp"
+    assert float((d.double().pow(2).sum() / a["gbf"].double().pow(2).sum()).sqrt()) <= 2e-3
+    assert abs(a["gnorm"] - b["gnorm"]) <= 1e-3 * a["gnorm"]
+    bad = ((a["p"] - b["p"]).abs() > 1e-5).float().mean().item()
+    assert bad <= 1e-2, bad
+    assert abs(a["loss2"] - b["loss2"]) <= 2e-3 * abs(a["loss2"])
+
+
 def _comm_direct_main(port, out_path):
     """libmicrodit_comm.so by itself on a one-rank communicator: every collective is the identity, what is checked is the stream
     contract -- a collective runs behind the kernels already enqueued on the caller's stream, the caller's later kernels run

@@ -90,6 +90,32 @@ def test_train_step_parity(hip, tag, cfgf, B, seed, ratio, pm, ps, cap):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("cfgf,B,seed,ratio,cap", [(orc.tiny_config, 4, 21, 0.75, 77), (orc.micro_config, 3, 22, 0.5, 20)])
+def test_head_major_qk_equals_packed(hip, cfgf, B, seed, ratio, cap):
+    """DiTEngine.qk_head_major (q / k as [B, H, S, hd] through md_qkln_fwd_hm / md_qkln_bwd_hm, off by default) is a LAYOUT: the same
+    kernels do the same arithmetic on the same values, so the loss must be bit-identical and every gradient equal to 1e-4 rel-RMS to the packed-row step
+    (self-attention, cross-attention with 77 / 20 caption tokens, the caption attention block)."""
+    cfg = cfgf()
+    sd = orc.synth_state_dict(cfg, seed)
+    batch, rnd, epsn, mnoise = orc.synth_batch(cfg, B, seed + 1, cap_len=cap)
+    gb = {k: v.cuda() for k, v in batch.items()}
+    noise = (rnd.cuda(), epsn.cuda(), mnoise.cuda())
+    condg = gb["caption_latents"] * gb["drop_caption_mask"].view(-1, 1, 1, 1).half()
+    got = {}
+    for hm in (False, True):
+        model = build_product(cfg, sd, -0.6, 1.2, ratio)
+        model.dit.engine.qk_head_major = hm
+        loss = model.edm_loss(gb["image_latents"], condg, mask_ratio=ratio, _noise=noise)
+        loss.backward()
+        torch.cuda.synchronize()
+        got[hm] = (loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.dit.named_parameters()})
+    assert torch.equal(got[True][0], got[False][0]), (got[True][0].item(), got[False][0].item())
+    # (a handful of reductions -- adaLN gate / shift sums -- use fp32 atomics: their order, not the layout, moves the last bits)
+    diff = {k: _rel_rms(got[True][1][k], got[False][1][k]) for k in got[False][1]}
+    bad = {k: v for k, v in diff.items() if v > 1e-4}
+    assert not bad, bad
+
+
 def _res512_cfg():
     """configs/res_512_*.yaml geometry on the Tiny widths: 64x64 latents (T = 1024 tokens), pos_interp_scale = 2."""
     return orc.tiny512_config()

@@ -140,6 +140,11 @@ def test_moe_grouped(hip, variant, Bk, d, f):
                 sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1, mode=hip.EPI_DACT, act=hip.ACT_GELU_ERF, dact_cached=1)
     _close(dHc, torch.einsum("erd,efd->erf", dO.float(), W2.float()) * Hd.float(), what="dact from the cached derivative")
     _close(dHc, dHp.float(), rel=2e-2, what="cached vs recomputed derivative")
+    # dact_cached is refused (-1, nothing launched) with any other activation, or on a forward launch without a C2 to hold the
+    # derivative: an inconsistent caller must not get the pre-activation multiplied in silently (every kernel family, one check)
+    bad = dict(M=Bk, N=f, K=d, lda=d, ldb=d, ldc=f, ldaux=f, sA=Bk * d, sB=f * d, sC=Bk * f, sAux=Bk * f, batch=E, a_kcontig=1, b_kcontig=1)
+    assert hip.gemm(dO, W2, dHc, aux=Hd, mode=hip.EPI_DACT, act=hip.ACT_GELU_TANH, dact_cached=1, expect=None, **bad) == -1
+    assert hip.gemm(dO, W2, dHc, act=hip.ACT_GELU_ERF, dact_cached=1, expect=None, **{k: v for k, v in bad.items() if k not in ("ldaux", "sAux")}) == -1
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
