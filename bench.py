@@ -11,8 +11,9 @@ Extra keys of the line (the headline fields are unchanged by them):
                  1 warm-up + 5 timed steps each at microbatch 256 (their YAMLs say 64 / 32: stated per stage), N = 1 only
                  (--no-other-stages skips them);
   value_mb256    the headline step with the YAML microbatch (256 = the per-rank shape of an 8-GPU run), N = 1 only;
-  value_mb256_cu248, n8_ceiling   the same with every persistent-GEMM grid limited to the 248 CUs an 8-channel RCCL kernel leaves
-                 (the rank-of-8 step emulated on one GPU) and 8 x that / the headline; `_whole_tiles` = without the split-K tail;
+  value_mb256_cu248   the same with every persistent-GEMM grid limited to the 248 CUs an 8-channel RCCL kernel leaves;
+  rank_of_8_step, n8_ceiling   ONE 256-image microbatch per step through the production sharded exchange on a one-rank RCCL communicator, 248 CUs
+                 (the rank-of-8 step emulated on one GPU) and 8 x that / the headline;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
                  the committed rocprofv3 PMC passes (profiles/r5_gemm_traffic.json: counters need rocprofv3 around the process,
                  so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
@@ -197,7 +198,54 @@ class Stage:
         torch.cuda.empty_cache()
 
 
-TRAFFIC_FILE = "r5_gemm_traffic.json"
+def rank_of_8_leg(head, steps=6, pretend_world=8, cu_limit=248):
+    """One rank of the 8-GPU run on ONE GPU (see the caller): returns {images_per_s (this rank's share), ms_per_step, ...}.  Uses the
+    headline stage's model / optimiser with a second Trainer (sharded bf16 exchange over a one-rank RCCL communicator)."""
+    from micro_diffusion_amd.trainer import Trainer
+    made_pg = False
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        made_pg = True
+    old_tr, old_batch, old_per = head.trainer, head.batch, head.per_rank
+    eng = head.model.dit.engine
+    saved_fn = eng.cu_limit_fn
+    try:
+        tr = Trainer(head.model, old_tr.opt, old_tr.schedule, clip_norm=old_tr.clip_norm, microbatch_size=256, exchange="bf16",
+                     single_rank_exchange=True, dp_mode="sharded")
+        tr.batches_seen = 100
+        tr.shard_chunk_of = pretend_world
+        tr.measure_comm = True
+        eng.cu_limit_fn = lambda: cu_limit
+        for ar in (eng._tape_arena, eng._scratch_arena):     # another launch sequence: the arenas are re-measured on its first pass
+            ar.peaks.clear()
+            ar.buf = None
+        head.trainer, head.batch, head.per_rank = tr, {k: v[:256] for k, v in old_batch.items()}, 256
+        e, loss = head.timed(steps, 2, 1)
+        res = {"images_per_s": 256 * steps / e, "ms_per_step": e / steps * 1e3, "steps": steps, "per_rank_batch": 256, "microbatches_per_step": 1,
+               "cu_limit": cu_limit, "adamw_share": f"1/{pretend_world} of every bucket", "gradient_launches_stored_as_bf16": tr.sync.last_stored,
+               "optimizer_ms": tr.optimizer_ms(last=steps), "exchange_wait_ms": tr.exposed_comm_ms(last=steps), "loss": loss,
+               "exchange": tr.sync.describe(), "collectives": "identities on a one-rank RCCL communicator (no byte crosses xGMI)"}
+        tr.sync.wait_gather()
+        tr.consolidate()
+        return res
+    finally:
+        eng.cu_limit_fn = saved_fn
+        head.trainer, head.batch, head.per_rank = old_tr, old_batch, old_per
+        head.model.dit._on_segment = old_tr.sync.on_segment
+        old_tr.sync.norm_partials = old_tr.opt.partials          # (ensure_norm_slots may have re-allocated them)
+        for ar in (eng._tape_arena, eng._scratch_arena):
+            ar.peaks.clear()
+            ar.buf = None
+        eng.before_segment = old_tr.sync.wait_gather if old_tr.sharded else None
+        head.model.dit.shadow_is_authoritative = False
+        if made_pg:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+
+
+TRAFFIC_FILE = "r6_gemm_traffic.json"
 
 
 def gemm_traffic():
@@ -393,25 +441,31 @@ def main():
         # shape of an 8-GPU run): the N = 1 figure an N = 8 scaling ratio has to be read against
         out["config"]["yaml_microbatch"] = 256
         out["config"]["value_at_yaml_microbatch"] = out["value_mb256"]
-        # ---- the rank-of-8 step emulated on ONE GPU: the same 256-image microbatches with every persistent-GEMM
-        # grid limited to the 248 CUs an 8-channel RCCL kernel leaves (what trainer.py does to a rank while a collective is in
-        # flight: at N = 8 that is nearly the whole step).  n8_ceiling = 8 x that rate / the headline: the scaling an 8-GPU run can
-        # reach before a single exposed byte.  `_whole_tiles` = the same with the split-K tail form of the GEMM switched off
-        # (256 tiles on 248 workgroups = two rounds): what the tail form buys.
+        # ---- the rank-of-8 step emulated on ONE GPU.  (i) value_mb256_cu248 (round-5 definition, kept for continuity): the same
+        # 256-image microbatches, 8 per step, with every persistent-GEMM grid limited to the 248 CUs an 8-channel RCCL kernel leaves.
+        # (ii) rank_of_8_step (round 6): what a rank of the 8-GPU run really executes -- ONE 256-image microbatch per optimiser step
+        # (configs/res_256_pretrain.yaml:24,111: 2048 / 8 = device_train_microbatch_size), the production sharded exchange on a
+        # one-rank RCCL communicator (every collective an identity; staging, side-stream norms, stream waits as shipped), weight
+        # gradients stored straight into the bf16 exchange buffer (DiTEngine.wgrad_bf16), AdamW over 1 / 8 of every bucket, all of
+        # it on 248 CUs.  n8_ceiling = 8 x rank_of_8_step / value: the scaling an 8-GPU run can reach before a single exposed byte.
         eng = head.model.dit.engine
-        saved_fn, saved_tail = eng.cu_limit_fn, eng.gemm_tail_mode
+        saved_fn = eng.cu_limit_fn
         eng.cu_limit_fn = lambda: 248
         e248, _ = head.timed(2, 1, 1)
         out["value_mb256_cu248"] = args.global_batch * 2 / e248
-        eng.gemm_tail_mode = 1
-        e248w, _ = head.timed(2, 1, 1)
-        out["value_mb256_cu248_whole_tiles"] = args.global_batch * 2 / e248w
-        eng.cu_limit_fn, eng.gemm_tail_mode = saved_fn, saved_tail
+        eng.cu_limit_fn = saved_fn
+        out["n8_ceiling_r5_definition"] = 8.0 * out["value_mb256_cu248"] / value
+        try:
+            out["rank_of_8_step"] = rank_of_8_leg(head)
+            out["n8_ceiling"] = 8.0 * out["rank_of_8_step"]["images_per_s"] / value
+            out["n8_ceiling_note"] = ("8 x rank_of_8_step.images_per_s / value: 8 ranks each running their one-microbatch step on 248 CUs "
+                                      "(sharded exchange path on a one-rank communicator), against the 1-GPU headline (microbatch %d); the "
+                                      "round-5 definition (8 x value_mb256_cu248 / value) is n8_ceiling_r5_definition" % args.microbatch)
+        except Exception as e:          # no RCCL communicator on this box: keep the round-5 number, say so
+            out["rank_of_8_step"] = {"images_per_s": None, "error": f"{type(e).__name__}: {e}"}
+            out["n8_ceiling"] = out["n8_ceiling_r5_definition"]
+            out["n8_ceiling_note"] = "rank_of_8_step failed: 8 x value_mb256_cu248 / value (round-5 definition)"
         eng = None
-        out["n8_ceiling"] = 8.0 * out["value_mb256_cu248"] / value
-        out["n8_ceiling_note"] = ("8 x value_mb256_cu248 / value: 8 ranks each running the 256-image step on 248 CUs, against the 1-GPU "
-                                  "headline (microbatch %d); against value_mb256 the same ratio is %.2f" %
-                                  (args.microbatch, 8.0 * out["value_mb256_cu248"] / out["value_mb256"]))
         head.trainer.microbatch_size = args.microbatch
     head.close()
     if world == 1 and not args.no_other_stages:

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--per-rank", type=int, default=256)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--pretend-world", type=int, default=8)
+    ap.add_argument("--cu-limit", type=int, default=0, help="limit every persistent-GEMM grid to this many CUs (248 = what 8 RCCL channels leave)")
+    ap.add_argument("--ab-store", action="store_true", help="sharded mode only: the one-microbatch bf16 store path off / on, alternating")
     a = ap.parse_args()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -34,16 +36,20 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from micro_diffusion_amd.trainer import Trainer
     st = bench.Stage("res_256_pretrain", "MicroDiT_XL_2", a.per_rank, a.per_rank, 1, 0)      # global batch = the rank's share
-    for mode in ("allreduce", "sharded"):
+    runs = [("sharded", 0), ("sharded", 1), ("sharded", 1), ("sharded", 0)] if a.ab_store else [("allreduce", 1), ("sharded", 1)]
+    for mode, store in runs:
         tr = Trainer(st.model, st.trainer.opt, st.trainer.schedule, clip_norm=st.trainer.clip_norm, microbatch_size=a.per_rank,
                      exchange="bf16", single_rank_exchange=True, dp_mode=mode)
         tr.batches_seen = 100
         tr.measure_comm = True
         if mode == "sharded":
             tr.shard_chunk_of = a.pretend_world
+        tr.sync.store_bf16 = bool(store)
+        if a.cu_limit:
+            st.model.dit.engine.cu_limit_fn = lambda lim=a.cu_limit: lim
         st.trainer = tr
         e, loss = st.timed(a.steps, 2, 1)
-        out = {"mode": mode, "per_rank_batch": a.per_rank, "ms_per_step": e / a.steps * 1e3, "rank_images_per_s": a.per_rank * a.steps / e,
+        out = {"mode": mode, "store_bf16": bool(store), "cu_limit": a.cu_limit, "gradient_launches_stored": tr.sync.last_stored, "per_rank_batch": a.per_rank, "ms_per_step": e / a.steps * 1e3, "rank_images_per_s": a.per_rank * a.steps / e,
                "optimizer_ms": tr.optimizer_ms(last=a.steps), "exchange_wait_ms": tr.exposed_comm_ms(last=a.steps),
                "buckets": tr.sync.last_buckets, "exchange": tr.sync.describe(),
                "note": ("AdamW over 1/%d of every bucket + the whole small region; collectives are identities on one rank" % a.pretend_world)
