@@ -39,7 +39,12 @@ enum md_epilogue {
     MD_EPI_STORE_F32 = 2,  /* C(f32)  = alpha*acc + bias                                                       */
     MD_EPI_ACCUM_F32 = 3,  /* C(f32) += alpha*acc + bias   (single writer per element)                         */
     MD_EPI_ATOMIC_F32 = 4, /* atomicAdd(C(f32), alpha*acc) (split-K weight gradients)                          */
-    MD_EPI_DACT = 5        /* C = bf16(alpha*acc * act'(aux))  (dgrad through an activation)                   */
+    MD_EPI_DACT = 5,       /* C = bf16(alpha*acc * act'(aux))  (dgrad through an activation)                   */
+    MD_EPI_SWIGLU_BWD = 6  /* ABI 6: the SwiGLU backward (dit.py:88-89) fused into the w3 data gradient da = dy W3: aux = h12
+                              [M, 2N] (ldaux), C = dh12 [M, 2N] (ldc); with g = bf16(acc): C[:, n] = g * h2 * silu'(h1),
+                              C[:, N + n] = g * silu(h1).  Built into the 4-wave kernel only (A K-contiguous, M % 256 == N % 256
+                              == 0, no cu_limit): any other problem returns MD_NOT_ELIGIBLE and launches nothing -- the caller
+                              then runs the plain data gradient + md_swiglu_bwd.                                  */
 };
 
 /* C[m,n] (+)= alpha * sum_k A(m,k) * B(n,k).  a_kcontig: A(m,k) = A[m*lda + k], else A[k*lda + m]; same for B

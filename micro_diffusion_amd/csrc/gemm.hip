@@ -619,13 +619,22 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     // num_experts) is allowed as long as the caller pads the rows to the next multiple of 8 with finite values
     // (zeros): whole chunks are read / written whenever their first element is in range.
     if (a->lda % 8 || a->ldb % 8) return MD_BAD_ARG;
-    if ((a->mode == MD_EPI_STORE_BF16 || a->mode == MD_EPI_RESIDUAL || a->mode == MD_EPI_DACT) ? (a->ldc % 8) : (a->ldc % 4))
+    if ((a->mode == MD_EPI_STORE_BF16 || a->mode == MD_EPI_RESIDUAL || a->mode == MD_EPI_DACT || a->mode == MD_EPI_SWIGLU_BWD) ? (a->ldc % 8) : (a->ldc % 4))
         return MD_BAD_ARG;
     if (a->C2 && a->ldc2 % 8) return MD_BAD_ARG;
     // split-K: either atomics into C, or every split stores its own fp32 slice (C + split * sSplit) for md_splitk_reduce
     if (a->ksplit > 1 && !(a->mode == MD_EPI_ATOMIC_F32 || (a->mode == MD_EPI_STORE_F32 && a->sSplit > 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_RESIDUAL && (!a->res || (a->gate && a->rows_per_sample <= 0))) return MD_BAD_ARG;
     if (a->mode == MD_EPI_DACT && !a->aux) return MD_BAD_ARG;
+    if (a->mode < MD_EPI_STORE_BF16 || a->mode > MD_EPI_SWIGLU_BWD) return MD_BAD_ARG;
+    if (a->mode == MD_EPI_SWIGLU_BWD) {
+        // the SwiGLU backward fused into the w3 data gradient: built into the 4-wave kernel only (interior tiles, free chip); any
+        // other problem is NOT_ELIGIBLE -- nothing is launched and the caller runs the plain data gradient + md_swiglu_bwd
+        if (!a->aux || a->ldaux % 8) return MD_BAD_ARG;
+        if (a->variant != MD_GEMM_AUTO && a->variant != MD_GEMM_W4) return MD_NOT_ELIGIBLE;
+        if (!md_gemm_w4_eligible(a) || (a->cu_limit > 0 && a->cu_limit < 256) || getenv("MD_GEMM_NO_W4")) return MD_NOT_ELIGIBLE;
+        a_copy.variant = MD_GEMM_W4;
+    }
     // dact_cached: C2 of the forward (STORE_BF16) holds gelu'(h) in place of h and the DACT launch multiplies by aux as it is -- both
     // sides only with the erf-GELU, the forward only with a C2 to write (every kernel family checks the same thing here, once)
     if (a->dact_cached && (a->act != MD_ACT_GELU_ERF || !(a->mode == MD_EPI_DACT || (a->mode == MD_EPI_STORE_BF16 && a->C2)))) return MD_BAD_ARG;

@@ -23,6 +23,7 @@ __device__ __forceinline__ float apply_dact(float v, int act) {
 
 // gemm_pp.hip
 bool md_gemm_pp_eligible(const md_gemm_args* a);
+bool md_gemm_pp_shape_ok(const md_gemm_args* a, int epi);
 int md_gemm_pp_launch(const md_gemm_args* a, hipStream_t stream);
 
 // gemm_w4.hip

@@ -747,6 +747,12 @@ static bool pp_instantiated(int akc, int bkc, int epi) {
 bool md_gemm_pp_eligible(const md_gemm_args* a) {
     const int epi = md_gemm_pp_epi_kind(a);
     if (epi < 0 || !pp_instantiated(a->a_kcontig, a->b_kcontig, epi)) return false;
+    return md_gemm_pp_shape_ok(a, epi);
+}
+
+// Everything md_gemm_pp_eligible asks of a problem except "this kernel family has the instantiation" (the w4 kernel shares the plan,
+// the ranges and the plain-epilogue rule, and builds one epilogue kind pp256 does not have).
+bool md_gemm_pp_shape_ok(const md_gemm_args* a, int epi) {
     if (a->K % a->ksplit) return false;
     const int64_t kspan = a->K / a->ksplit;
     if (kspan < 128 || kspan % 128) return false;
@@ -763,7 +769,7 @@ bool md_gemm_pp_eligible(const md_gemm_args* a) {
     }
     if (a->A_list && a->list_segments > 1 && (kspan % ((int64_t)a->list_segments * 128))) return false;   // whole k-tile pairs per segment
     if (epi == PP_E_RES && a->gate && a->rows_per_sample % 64) return false;   // one gate row per 64-row quadrant
-    if ((epi == PP_E_RES || pp_is_dact(epi)) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
+    if ((epi == PP_E_RES || pp_is_dact(epi) || epi == PP_E_DACT_SWIGLU) && (a->bias || a->alpha != 1.f || a->M % PT || a->N % PT))
         return false;                                            // only the PLAIN form of these two epilogues is built
     if (a->M >= (1 << 30) || a->N >= (1 << 30) || a->K >= (1 << 30)) return false;
     if (a->lda > (1 << 22) || a->ldb > (1 << 22)) return false;  // 32-bit per-lane DMA offsets

@@ -186,7 +186,9 @@ enum {
     PP_E_DACT_GELU = 3,  // MD_EPI_DACT through GELU(erf)               (the MoE fc1 dgrad)
     PP_E_F32 = 4,        // MD_EPI_STORE_F32                            (+ bias; split-K slices)
     PP_E_BF16_GELU_D = 5,  // MD_EPI_STORE_BF16, GELU(erf), dact_cached: C2 = gelu'(pre-activation) instead of the pre-activation
-    PP_E_DACT_MUL = 6      // MD_EPI_DACT, dact_cached: C = acc * aux  (aux = the cached derivative)
+    PP_E_DACT_MUL = 6,     // MD_EPI_DACT, dact_cached: C = acc * aux  (aux = the cached derivative)
+    PP_E_DACT_SWIGLU = 7   // MD_EPI_SWIGLU_BWD: the SwiGLU backward fused into the w3 data gradient (w4 kernel only):
+                           //   aux = h12 [M, 2N], C = dh12 [M, 2N]:  C[:, n] = da * h2 * silu'(h1),  C[:, N + n] = da * silu(h1),  da = bf16(acc)
     // MD_EPI_ACCUM_F32 stays on the gemm.hip kernels: its operand (32 fp32 per lane and quadrant) does not fit beside the
     // fragments, and without the one-phase-ahead prefetch each quadrant would drain the DMA ring.
 };
@@ -355,6 +357,7 @@ inline int md_gemm_pp_epi_kind(const md_gemm_args* a) {
         case MD_EPI_RESIDUAL: return PP_E_RES;
         case MD_EPI_DACT: return a->act == MD_ACT_GELU_ERF ? (a->dact_cached ? PP_E_DACT_MUL : PP_E_DACT_GELU) : -1;
         case MD_EPI_STORE_F32: return PP_E_F32;
+        case MD_EPI_SWIGLU_BWD: return PP_E_DACT_SWIGLU;
         default: return -1;
     }
 }

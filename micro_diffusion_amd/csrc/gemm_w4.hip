@@ -49,7 +49,7 @@ constexpr int W4_BUF = 32768;      // bytes of one operand of one k-tile buffer:
 constexpr int W4_BREG = 65536;     // B buffers start here
 constexpr int W4_SLAB = 8192;      // epilogue slab of one wave (behind the k-tile buffers)
 
-constexpr bool w4_is_dact(int epi) { return epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL; }
+constexpr bool w4_is_dact(int epi) { return epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL || epi == PP_E_DACT_SWIGLU; }
 
 
 
@@ -91,6 +91,7 @@ struct W4EpiLane {
 struct W4Ops {
     uint4 v[4];
     uint4 gq;
+    uint4 v2[4];          // PP_E_DACT_SWIGLU: h2 (aux columns N + n) beside h1 in v (unused members cost the other kinds nothing)
 };
 
 template <int EPI>
@@ -125,6 +126,8 @@ template <int EPI, bool INTERIOR>
 __device__ __forceinline__ void w4_epi_req(const md_gemm_args& p, const W4Tile& et, const W4EpiLane& L, const char* oprow, int row0, int wcol, uint4& dst) {
     if (INTERIOR) {
         dst = *reinterpret_cast<const uint4*>(oprow + L.oo);       // oprow = &op[wave tile row row0, wave tile column 0]
+    } else if constexpr (EPI == PP_E_DACT_SWIGLU) {
+        dst = make_uint4(0u, 0u, 0u, 0u);                             // (interior tiles only: md_gemm_pp_shape_ok)
     } else {                                                          // ragged tile: every lane's row clamped into the matrix
         const int64_t ldo = EPI == PP_E_RES ? p.ldr : p.ldaux;
         const int row = row0 + L.rg < et.mlim - 1 ? row0 + L.rg : et.mlim - 1;
@@ -218,6 +221,22 @@ __device__ __forceinline__ void w4_epi_store(const md_gemm_args& p, const PPPlan
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= ax[e];
             out = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+        } else if constexpr (EPI == PP_E_DACT_SWIGLU) {
+            // da = bf16(acc); dh1 = da * h2 * silu'(h1) -> C[:, n], dh2 = da * silu(h1) -> C[:, N + n]   (elementwise.hip: swiglu_bwd8)
+            float g[8], x1[8], x2[8], o2[8];
+            unpack8(T, g);
+            unpack8(ops.v[t], x1);
+            unpack8(ops.v2[t], x2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x1[e] * -1.4426950408889634f));
+                const float sl = x1[e] * sg;
+                o2[e] = g[e] * sl;
+                g[e] = g[e] * x2[e] * (sg + sl * (1.f - sg));
+            }
+            out = make_uint4(cvt_pk_bf16(g[0], g[1]), cvt_pk_bf16(g[2], g[3]), cvt_pk_bf16(g[4], g[5]), cvt_pk_bf16(g[6], g[7]));
+            if (ok) *reinterpret_cast<uint4*>(crow + L.oc + 2 * (int64_t)p.N) =
+                make_uint4(cvt_pk_bf16(o2[0], o2[1]), cvt_pk_bf16(o2[2], o2[3]), cvt_pk_bf16(o2[4], o2[5]), cvt_pk_bf16(o2[6], o2[7]));
         } else if constexpr (EPI == PP_E_DACT_GELU) {
             float v[8], ax[8];
             unpack8(T, v);
@@ -235,8 +254,10 @@ __device__ __forceinline__ void w4_epi_store(const md_gemm_args& p, const PPPlan
 #else
         if (ok) *reinterpret_cast<uint4*>(crow + L.oc) = out;
 #endif
-        if constexpr ((EPI == PP_E_RES || w4_is_dact(EPI)) && I < 7)      // this piece is consumed: request the next row group's
+        if constexpr ((EPI == PP_E_RES || w4_is_dact(EPI)) && I < 7) {    // this piece is consumed: request the next row group's
             w4_epi_req<EPI, INTERIOR>(p, et, L, R.op, row0 + 16, wcol, ops.v[t]);
+            if constexpr (EPI == PP_E_DACT_SWIGLU) w4_epi_req<EPI, INTERIOR>(p, et, L, R.op + 2 * (int64_t)p.N, row0 + 16, wcol, ops.v2[t]);
+        }
         R.c += R.sc;
         R.c2 += R.sc2;
         R.op += R.so;
@@ -269,6 +290,7 @@ __device__ __forceinline__ void w4_epilogue(const md_gemm_args& p, const PPPlan&
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             w4_epi_req<EPI, INTERIOR>(p, et, L, R.op, wrow + 4 * t, wcol, ops.v[t]);
+            if constexpr (EPI == PP_E_DACT_SWIGLU) w4_epi_req<EPI, INTERIOR>(p, et, L, R.op + 2 * (int64_t)p.N, wrow + 4 * t, wcol, ops.v2[t]);
             R.op += R.so;
         }
         if constexpr (EPI == PP_E_RES) w4_epi_gate<EPI, 0>(p, w, et, L, wrow, wcol, ops.gq);
@@ -455,17 +477,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
 }  // namespace
 
 // Instantiated: NT (nn.Linear forward) bf16 / gated residual / activation derivative; NN (dgrads, the MoE's [E, in, out] experts) bf16 /
-// GELU(erf) with the raw copy or the cached derivative / residual.
+// GELU(erf) with the raw copy or the cached derivative / residual / the SwiGLU backward (the w3 data gradient).
 static bool w4_instantiated(int bkc, int epi) {
     if (bkc) return epi == PP_E_BF16 || epi == PP_E_RES || epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL;
-    return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_BF16_GELU_D || epi == PP_E_RES;
+    return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_BF16_GELU_D || epi == PP_E_RES || epi == PP_E_DACT_SWIGLU;
 }
 
 bool md_gemm_w4_eligible(const md_gemm_args* a) {
     if (!a->a_kcontig) return false;
     const int epi = md_gemm_pp_epi_kind(a);
     if (epi < 0 || !w4_instantiated(a->b_kcontig, epi)) return false;
-    if (!md_gemm_pp_eligible(a)) return false;                   // K span, N % 8, leading-dimension ranges, gate rows, ...
+    if (!md_gemm_pp_shape_ok(a, epi)) return false;              // K span, N % 8, leading-dimension ranges, gate rows, interior tiles, ...
+    if (epi == PP_E_DACT_SWIGLU && (!a->aux || a->batch != 1 || a->ldaux < 2 * a->N || a->ldc < 2 * a->N)) return false;
     if (a->ksplit != 1 || a->A_list || a->B_list || a->problems || a->timeline) return false;
     if (a->bias || a->alpha != 1.f) return false;                // only the plain form of every epilogue is built
     if (!a->b_kcontig && (a->K * a->ldb >= (int64_t)1 << 30)) return false;   // 32-bit scalar byte offset of the K-strided cursor
@@ -490,6 +513,7 @@ int md_gemm_w4_launch(const md_gemm_args* a, hipStream_t stream) {
         if (epi == PP_E_BF16) W4_LAUNCH(0, PP_E_BF16);
         else if (epi == PP_E_BF16_GELU) W4_LAUNCH(0, PP_E_BF16_GELU);
         else if (epi == PP_E_BF16_GELU_D) W4_LAUNCH(0, PP_E_BF16_GELU_D);
+        else if (epi == PP_E_DACT_SWIGLU) W4_LAUNCH(0, PP_E_DACT_SWIGLU);
         else W4_LAUNCH(0, PP_E_RES);
     }
 #undef W4_LAUNCH

@@ -149,6 +149,7 @@ class DiTEngine:
         # GradSync -- by the split-K reduction (or the GEMM epilogue when nothing is split): no read-modify-write of the fp32
         # accumulator, no cast + clear pass afterwards.  (g_lo, g_hi, gbf address, {fp32 address: elements stored} of this step)
         self.wgrad_bf16 = None
+        self.fuse_swiglu_bwd = os.environ.get("MD_FUSE_SWIGLU_BWD", "1") != "0"   # A/B: 0 = data gradient + md_swiglu_bwd as two launches
         self.cu_limit_fn = None     # data parallelism: callable() -> CUs the persistent GEMM may occupy right now (0 = all): the
         #                             Trainer leaves the CUs of RCCL's channels free while a collective is in flight
 
@@ -236,6 +237,7 @@ class DiTEngine:
     def _gemm(self, **kw):
         a = hip.GemmArgs()
         problems = kw.pop("_problems", None)      # grouped launch: the problem dicts (accounting only; the table is in kw["problems"])
+        may_refuse = kw.pop("_try", False)        # True: a launch the library may refuse (NOT_ELIGIBLE, nothing launched) -> returns False
         for k, v in kw.items():
             setattr(a, k, v)
         prof = self.gemm_profile
@@ -259,6 +261,8 @@ class DiTEngine:
                 a.variant = hip.GEMM_AUTO
         if rc == hip.NOT_ELIGIBLE:
             rc = self.L.md_gemm_bf16(byref(a), self._st())
+        if rc == hip.NOT_ELIGIBLE and may_refuse:
+            return False
         hip.check(rc, "md_gemm_bf16")
         if self.gemm_log is not None:      # the kernel the library actually launched (written back through chosen_variant)
             self.gemm_log.append((chosen.value, a.M, a.N, a.K, a.batch))
@@ -269,6 +273,8 @@ class DiTEngine:
             mn = a.M * a.N * a.batch
             byt = 2.0 * (a.M * a.K + a.N * a.K) * a.batch + mn * out_b * a.ksplit
             byt += mn * 2 * ((1 if a.C2 else 0) + (1 if a.res else 0) + (1 if a.aux else 0)) + (mn * 4 if a.mode == hip.EPI_ACCUM_F32 else 0)
+            if a.mode == hip.EPI_SWIGLU_BWD:
+                byt += mn * 2 * 2            # h2 beside h1, dh2 beside dh1
             fl = 2.0 * a.M * a.N * a.K * a.batch
             key = (a.M, a.N, a.K, a.batch, a.a_kcontig, a.b_kcontig, a.ksplit)
             if problems:
@@ -277,6 +283,7 @@ class DiTEngine:
                 byt = 2.0 * a.K * sum(g["M"] + g["N"] for g in problems) + mn * 4 * a.ksplit
                 key = (-len(problems), mn // 1024, a.K, 1, 0, 0, a.ksplit)
             prof.append((e0, e1, fl, key, byt))
+        return True
 
     def lin_fwd(self, x, wname, out, M, N, K, *, ldx=None, ldc=None, mode=hip.EPI_STORE_BF16, act=0, res=None,
                 gate=None, ldg=0, rps=0, C2=None, ldc2=0, xoff=0, ooff=0, bias=True):
@@ -717,10 +724,17 @@ class DiTEngine:
         dxm3 = self.empty(M, d)
         if not bp.moe:
             self.lin_wgrad(dbr3, t.a, n + ".mlp.w3", M, d, f, defer=True)
-            da = self.empty(M, f)
-            self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
             dh12 = self.empty(M, 2 * f)
-            self._prof("swiglu", 10.0 * M * f, lambda: hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd"))
+            # da = dbr3 @ W3 with the SwiGLU backward in the GEMM epilogue (MD_EPI_SWIGLU_BWD: h12 read, dh12 written by the launch
+            # that forms da -- da never exists in memory, md_swiglu_bwd's pass over 10 bytes per element is gone); the library
+            # refuses what its 4-wave kernel does not cover (ragged tiles, a CU hold): then the two separate launches
+            fused = self.fuse_swiglu_bwd and self._gemm(
+                A=dbr3.data_ptr(), B=self.S[n + ".mlp.w3.weight"].data_ptr(), C=dh12.data_ptr(), aux=t.h12.data_ptr(), M=M, N=f, K=d, lda=d,
+                ldb=f, ldc=2 * f, ldaux=2 * f, batch=1, ksplit=1, a_kcontig=1, b_kcontig=0, mode=hip.EPI_SWIGLU_BWD, act=0, alpha=1.0, _try=True)
+            if not fused:
+                da = self.empty(M, f)
+                self.lin_dgrad(dbr3, n + ".mlp.w3", da, M, d, f)
+                self._prof("swiglu", 10.0 * M * f, lambda: hip.check(L.md_swiglu_bwd(da.data_ptr(), f, t.h12.data_ptr(), 2 * f, dh12.data_ptr(), 2 * f, M, f, st), "swiglu_bwd"))
             if self._fused12(n + ".mlp"):
                 self.lin_wgrad(dh12, t.xm3, n + ".mlp.w1", M, 2 * f, d, defer=True)
                 self.lin_dgrad(dh12, n + ".mlp.w1", dxm3, M, 2 * f, d)

@@ -24,7 +24,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-
 
 # enums (mirror include/microdit_hip.h)
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
-EPI_STORE_BF16, EPI_RESIDUAL, EPI_STORE_F32, EPI_ACCUM_F32, EPI_ATOMIC_F32, EPI_DACT = 0, 1, 2, 3, 4, 5
+EPI_STORE_BF16, EPI_RESIDUAL, EPI_STORE_F32, EPI_ACCUM_F32, EPI_ATOMIC_F32, EPI_DACT, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5, 6
 GEMM_AUTO, GEMM_REG128, GEMM_DMA128, GEMM_PACED256, GEMM_PP256, GEMM_W4 = 0, 1, 2, 3, 4, 5
 GEMM_VARIANT_NAMES = {"auto": 0, "reg128": 1, "dma128": 2, "paced256": 3, "pp256": 4, "w4": 5}
 # md_attn_args.bwd_split: backward kernel selector (0 = the library's rule; the others force a kernel: tests, A/B runs)

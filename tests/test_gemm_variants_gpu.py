@@ -147,6 +147,49 @@ def test_moe_grouped(hip, variant, Bk, d, f):
     assert hip.gemm(dO, W2, dHc, act=hip.ACT_GELU_ERF, dact_cached=1, expect=None, **{k: v for k, v in bad.items() if k not in ("ldaux", "sAux")}) == -1
 
 
+@pytest.mark.parametrize("M,f,d", [(16384, 2816, 1024), (4096, 768, 512), (65536, 2816, 1024)])
+def test_swiglu_bwd_fused_in_the_w3_dgrad(hip, M, f, d):
+    """MD_EPI_SWIGLU_BWD (ABI 6): da = dy @ W3 with the SwiGLU backward in the epilogue of the 4-wave kernel -- aux = h12 [M, 2f],
+    C = dh12 [M, 2f]: dh1 = da * h2 * silu'(h1), dh2 = da * silu(h1) with da = bf16(accumulator) -- against (i) torch fp32 autograd of
+    silu(h1) * h2 (dit.py:88-89) and (ii) the two-launch path it replaces (plain data gradient + md_swiglu_bwd), which rounds at the
+    same points.  What the kernel does not cover (ragged tiles, a CU hold, any other variant) is refused with NOT_ELIGIBLE and writes
+    nothing."""
+    torch.manual_seed(M + f)
+    L, st = hip.lib(), hip.stream_ptr()
+    dy = (torch.randn(M, d, device=dev) * 0.5).to(torch.bfloat16)
+    W3 = (torch.randn(d, f, device=dev) * 0.05).to(torch.bfloat16)            # torch layout [out = d, in = f]: the K-strided operand
+    h12 = torch.randn(M, 2 * f, device=dev).to(torch.bfloat16)
+    dh12 = torch.full((M, 2 * f), float("nan"), device=dev, dtype=torch.bfloat16)
+    kw = dict(M=M, N=f, K=d, lda=d, ldb=f, ldc=2 * f, ldaux=2 * f, a_kcontig=1, b_kcontig=0, mode=hip.EPI_SWIGLU_BWD)
+    chosen = []
+    rc = hip.gemm(dy, W3, dh12, aux=h12, expect=None, chosen=chosen, **kw)
+    assert rc == 0 and chosen[-1] == hip.GEMM_W4, (rc, chosen)
+    torch.cuda.synchronize()
+    # (ii) the two launches
+    da = torch.empty(M, f, device=dev, dtype=torch.bfloat16)
+    hip.gemm(dy, W3, da, M=M, N=f, K=d, lda=d, ldb=f, ldc=f, a_kcontig=1, b_kcontig=0)
+    two = torch.empty_like(dh12)
+    hip.check(L.md_swiglu_bwd(da.data_ptr(), f, h12.data_ptr(), 2 * f, two.data_ptr(), 2 * f, M, f, st), "swiglu_bwd")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dh12.float()).all()
+    d2 = (dh12.float() - two.float()).abs()
+    assert float((d2 > 0.0079 * two.float().abs() + 1e-6).float().mean()) <= 2e-3, "fused vs two launches: more than 2e-3 of the elements differ by more than a bf16 ulp"
+    # (i) torch fp32
+    rows = slice(0, 2048)
+    hr = h12[rows].float().requires_grad_(True)
+    a = torch.nn.functional.silu(hr[:, :f]) * hr[:, f:]
+    a.backward(dy[rows].float() @ W3.float())
+    _close(dh12[rows], hr.grad, rel=2e-2, what="swiglu bwd fused")
+    # refusals: another variant, a CU hold, ragged rows -- nothing is launched, nothing written
+    guard = torch.full_like(dh12, 3.0)
+    assert hip.gemm(dy, W3, guard, aux=h12, expect=None, variant=hip.GEMM_PP256, **kw) == hip.NOT_ELIGIBLE
+    assert hip.gemm(dy, W3, guard, aux=h12, expect=None, cu_limit=248, **kw) == hip.NOT_ELIGIBLE
+    kr = dict(kw, M=M - 8)
+    assert hip.gemm(dy, W3, guard, aux=h12, expect=None, **kr) == hip.NOT_ELIGIBLE
+    torch.cuda.synchronize()
+    assert float((guard.float() - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("Nw,Kw,T,E,ks", [(1024, 1024, 65536, 1, 16), (768, 3072, 65536, 8, 4), (2048, 1024, 78848, 1, 8),
                                           (3072, 1024, 16384, 1, 8), (520, 264, 4096, 3, 4)])
