@@ -10,10 +10,13 @@
 //   * v_mfma_f32_16x16x32_bf16 instead of 32x32x16: these kernels are POWER-bound (shader clock 1.42 GHz of 2.4 at 8192^3 with the
 //     matrix pipes 80 % busy, profiles/r6_w4_v1_experiments.txt) and the 16 x 16 form moves half the accumulator bytes per flop:
 //     +7 % on the whole instruction stream, +13 % MFMA-only;
-//   * ONE barrier per k-tile (64 deep) instead of eight;
-//   * operands are staged through REGISTERS (buffer_load_dwordx4 -> ds_write_b128), not by LDS-DMA: a DMA piece costs its
-//     issuing wave 60-185 cycles among MFMAs (MI355X_MICROARCH.md, per-instruction constants) -- hidden in pp256 by the partner
-//     wave, fatal with one wave per SIMD.  The loads of k-tile t + 2 are issued while k-tile t is multiplied;
+//   * TWO barriers per k-tile (64 deep) instead of eight;
+//   * operands are staged by LDS-DMA (buffer_load_dwordx4 ... offen lds: 16 per wave and k-tile, spread one per ~6 MFMAs, the loads
+//     of k-tile t + 2 issued while k-tile t is multiplied) and ALL 16 fragments of a k-step are resident (128 registers), so the
+//     k-tile's LDS buffer is free for the next DMA an eighth into the k-tile.  (The round's first form staged through 64 registers,
+//     buffer_load -> ds_write_b128, on the guide's warning that a DMA piece costs its issuing wave 60-185 cycles; at this density it
+//     does not -- the DMA form is +4 % on hot operands, +0.7-1.0 % on the step: profiles/r6_w4_lds_dma.txt.  It is also what the
+//     library's own NT kernel does.);
 //   * the epilogue goes through a private 8 KiB LDS slab per wave (the 32 KiB the two k-tile buffers leave of the 160): every
 //     global store of the kernel is 16 lanes x 16 bytes = 256 contiguous bytes of one output row (pp256: 64-byte runs).
 // The k-loop is generated inline asm on literal registers (gemm_w4_acc.inc <- scripts/gen_w4_acc.py: register plan, schedule and the
@@ -35,9 +38,8 @@ namespace {
 struct W4Addr {
     unsigned adA[2];     // A fragment reads: [k-step]; row lane % 16 (+ 16 i: immediate), 16-byte chunk (4 ks + lane / 16) ^ swizzle
     unsigned adB[8];     // B K-contiguous: [k-step] as A ([2..7] unused).  B K-strided: [column fragment j], the k-step is an immediate
-    unsigned wrA;        // staging writes of the A pieces (piece x: + x * 4096)
-    unsigned wrB[2];     // ... of the B pieces; K-strided B: [piece parity] (the k-row swizzle differs)
     unsigned aofs[8], bofs[8];   // global byte offsets of this thread's 8 pieces of each operand, relative to the tile's descriptor
+    unsigned ldsw;       // LDS address of this wave's 1 KiB inside a 4 KiB piece (M0 of its DMA loads = ldsw + buffer + 4096 x: immediates)
 };
 
 #ifndef W4_ACC_INC          // (kernel experiments build with another generated schedule: scripts/build_w4_variant.sh)
@@ -77,7 +79,7 @@ struct W4Tile {
 // to the other half while they fly, then group I is finished and stored (the first version waited for every read separately: 32
 // serialized LDS round trips per tile).  Per-lane offsets are formed once per tile (W4EpiLane); rows advance by scalar arithmetic.
 // bf16(acc) first (= what nn.Linear returns under autocast), then the fused arithmetic on that value, as in gemm_pp.hip.
-// Before the FIRST store of a tile every VM load issued so far (the k-loop's staging loads, the first operand requests) is waited
+// Before the FIRST store of a tile every VM load issued so far (the k-loop's DMA loads, the first operand requests) is waited
 // for: the next k-tile's LDS writes then need no vmcnt (gen_w4_acc.py, FRESH) and no store ever stands between a load and its wait.
 // ---------------------------------------------------------------------------------------------------------------------
 struct W4EpiLane {
@@ -308,8 +310,8 @@ __device__ __forceinline__ void w4_epilogue(const md_gemm_args& p, const PPPlan&
 
 // amdgpu_num_vgpr(144): hipcc's values that live across the k-loop are below v96 by construction (every k-loop statement clobbers
 // v[96:255]); inside an epilogue it may use v[96:143], which hold nothing then (gen_w4_acc.py register plan).  A budget of 96 was
-// overrun -- not spilled -- by the instantiations with the heaviest epilogues (v96 / v97 handed out as temporaries: then the first
-// staging register).  scripts/check_w4_asm.py (tests/test_build_static.py) audits every build for v144+ / accumulator use.
+// overrun -- not spilled -- by the instantiations with the heaviest epilogues (v96 / v97 handed out as temporaries: registers the k-loop
+// owns).  scripts/check_w4_asm.py (tests/test_build_static.py) audits every build for v144+ / accumulator use.
 template <int BKC, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_BREG + 4 * W4_SLAB];   // 160 KiB: the whole LDS of a CU
@@ -359,18 +361,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
             for (int j = 2; j < 8; ++j) ad.adB[j] = 0;
         }
     }
-    // staging writes.  K-contiguous operand: piece x (0..7) = rows x * 32 + tid / 8, logical chunk tid % 8.
-    // K-strided operand: piece x = k-rows x * 8 + tid / 32, logical chunk tid % 32 (a wave loads two whole 512-byte k-rows).
-    ad.wrA = lds0 + (unsigned)((tid >> 3) * 128 + ((((tid & 7) ^ ((tid >> 4) & 7))) << 4));
-    if (BKC) {
-        ad.wrB[0] = ad.wrA + W4_BREG;
-        ad.wrB[1] = ad.wrB[0];
-    } else {
-        const int t5 = tid >> 5, c = tid & 31;
-#pragma unroll
-        for (int par = 0; par < 2; ++par)          // k-row = 8 x + t5: k & 3 = t5 & 3, (k >> 3) & 1 = x & 1
-            ad.wrB[par] = lds0 + (unsigned)(W4_BREG + t5 * 512 + ((c ^ (((t5 & 3) << 1) | (par << 3))) << 4));
-    }
+    ad.ldsw = lds0 + (unsigned)wave * 1024u;
+    // DMA pieces.  K-contiguous operand: piece x (0..7) = rows x * 32 + tid / 8, PHYSICAL chunk tid % 8 (= lane-linear: wave w writes
+    // rows x * 32 + 8 w .. + 7).  K-strided operand: piece x = k-rows x * 8 + tid / 32, physical chunk tid % 32 (a wave loads two whole
+    // 512-byte k-rows).  The logical chunk each lane fetches is formed in stager_open.
 
     // ---- load cursor: runs two k-tiles (one pair) ahead of the multiplications, across tile boundaries.  nk is even, so the
     // cursor changes tiles only at the bottom of the pair loop; inside a k-tile it only steps its scalar byte offset.
@@ -380,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
     auto stager_open = [&](int n) {
         int m0, n0, batch, split;
         work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
-        const int c = (tid & 7) * 8;
+        const int c = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;   // a DMA lane sits at PHYSICAL chunk tid % 8 of its row: it fetches the logical chunk the swizzle puts there
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int row = x * 32 + (tid >> 3);
@@ -392,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
                 gb = (gb < w.N ? gb : w.N - 1) - n0;
                 ad.bofs[x] = (unsigned)(gb * w.ldb + c) * 2u;
             } else {                                       // k-row 8 x + tid / 32, columns 8 (tid % 32) .. (clamped to the last whole chunk)
-                int gc = n0 + (tid & 31) * 8;
+                int gc = n0 + ((tid & 31) ^ ((((tid >> 5) & 3) << 1) | ((x & 1) << 3))) * 8;     // physical chunk tid % 32 <- logical chunk ^ swz(k-row)
                 const int last = (w.N - 1) & ~7;
                 gc = (gc < last ? gc : last) - n0;
                 ad.bofs[x] = (unsigned)((x * 8 + (tid >> 5)) * w.ldb + gc) * 2u;
@@ -417,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
         }
     };
     // ---- the k-loop is generated inline asm on literal registers (gemm_w4_acc.inc, scripts/gen_w4_acc.py).
-    // prologue: k-tile 0 into buffer 0, k-tile 1 into the staging registers (landed), fragments of k-step 0
+    // prologue: k-tile 0 into buffer 0 (landed), k-tile 1 into buffer 1 (in flight), fragments of k-tile 0's k-step 0
     stager_open(0);
     w4_prologue<BKC>(ad, rA, rB, 0, 0, BKT * 2, kstepB);
     s_koffA = 2 * BKT * 2;
@@ -426,10 +420,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
     w4_first_reads<BKC>(ad);
 
     int c_n = 0, c_kt = 0;
-    // One k-tile: entering, A set 0 / B slot 0 hold k-step 0 of this k-tile (buffer BUF; the reads possibly still in flight) and the
-    // staging registers hold k-tile t + 1.  During H0..H2 the staging registers are written to the other buffer (free since the
-    // barrier of the previous k-tile) and re-loaded with k-tile t + 2; the barrier in front of H3 publishes them and frees buffer
-    // BUF for the next k-tile's writes; H3 reads the next k-tile's first fragments.  FRESH = first k-tile of an output tile.
+    // One k-tile (scripts/gen_w4_acc.py): entering, the k-step-0 registers hold this k-tile's first fragments (buffer BUF; the reads possibly
+    // still in flight) and the DMA loads of k-tile t + 1 are in flight into BUF ^ 1.  h0: first MFMAs + the k-step-1 fragment reads, barrier
+    // (BUF is free); h1: the DMA loads of k-tile t + 2 (the cursor's) into BUF, vmcnt + barrier (k-tile t + 1 has landed); h2: the last MFMAs
+    // + the next k-tile's first fragments.  FRESH = first k-tile of an output tile.
 #define W4_KTILE(BUF, FRESH)                                                                                            \
     do {                                                                                                                \
         w4_h0<BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                           \

@@ -1,5 +1,5 @@
 """Static audit of the built w4 GEMM (tests/test_build_static.py runs it): outside the generated inline asm hipcc must not touch
-v[144:255] (staging registers and the fragments that are live across an epilogue; v[96:143] are dead there and may be used) or any
+v[144:255] (the fragments that are live across an epilogue and the tail of the k-step-1 set; v[96:143] are dead there and may be used) or any
 accumulator register (they belong to the k-loop: scripts/gen_w4_acc.py), and nothing may be spilled to scratch.
     python scripts/check_w4_asm.py [<gemm_w4 .s file>]     (without an argument: compiles gemm_w4.hip to assembly first; exit code 0 = ok)"""
 import os

@@ -1,71 +1,70 @@
-"""Generates micro_diffusion_amd/csrc/gemm_w4_acc.inc: the hand-scheduled k-loop of the w4 GEMM (gemm_w4.hip) as inline asm.
+"""Generates micro_diffusion_amd/csrc/gemm_w4_acc.inc: the k-loop of the 4-wave GEMM (gemm_w4.hip) as inline asm on LITERAL registers.
 
-Register plan of the kernel (one wave per SIMD, the whole 512-register file):
+Operands are staged by LDS-DMA: `buffer_load_dwordx4 <offset>, <descriptor>, <k offset> offen lds` moves 64 lanes x 16 bytes from global
+memory straight to the 1 KiB of LDS at M0 -- no staging registers, no ds_write.  (The round's first form staged through 64 registers:
+buffer_load -> ds_write_b128.  Its ablations priced the LDS writes at 6 % and the loads at 10-13 % of the kernel; the library's own NT kernel,
+disassembled from its code object, runs 16 such DMA loads, 32 ds_read_b128 and 128 v_mfma_f32_16x16x32_bf16 per 64-deep k-tile with all
+16 fragments of a k-step resident and the LDS buffer released early in the k-tile.  This form: +4 % on hot operands, +0.7 % / +1.0 % on the
+full step at microbatch 1024 / 256 in same-box A/Bs, profiles/r6_w4_lds_dma.txt.)
+
+Register plan (one wave per SIMD, the whole 512-register file):
     a[0:255]    64 accumulator blocks of 16 x 16 fp32: block (i, j) = a[4 (8 i + j) : +3] (row fragment i, column fragment j of the wave's
                 128 x 128 tile; v_mfma_f32_16x16x32_bf16 with swapped operands, D = B A^T: lane l holds row l % 16, columns 4 (l / 16) + r)
-    v[96:127]   A fragments of k-step 1: FA[1][i] = v[96 + 4 i : +3], i = 0..7        } dead while an epilogue runs (re-read in H1 / H0
-    v[128:143]  B fragments, slot 1:     FB[1][q] = v[128 + 4 q : +3]                  } before their next use)
-    v[144:207]  staging registers ST[x] = v[144 + 4 x : +3]: pieces 0..7 of the A k-tile, 8..15 of the B k-tile (16 bytes per lane each)
-    v[208:239]  A fragments of k-step 0: FA[0][i]
-    v[240:255]  B fragments, slot 0:     FB[0][q].  A k-step is multiplied in two HALVES of 32 MFMAs (column fragments j = 4 h + q);
-                half n of the stream uses slot n % 2 while the other slot is re-read
-    v[0:95]     hipcc's across the k-loop (addresses, loop state): every k-loop statement clobbers v[96:255], so nothing of the compiler's
-                can live there across one.  Inside an epilogue hipcc may spread into v[96:143] (amdgpu_num_vgpr(144): it was seen to overrun
-                a lower budget instead of spilling, into what then were the staging registers); scripts/check_w4_asm.py audits that no
-                compiler instruction names v144+ or an accumulator register.  The registers above are named literally and listed as
-                clobbers (that also sizes the kernel descriptor).
-Why asm: handed the same stream as plain loads / LDS accesses (or as asm with tied "+v" operands), hipcc gave every re-load of a staging
-or fragment register a fresh physical register, ran out of registers and spilled staging registers behind a vmcnt(0) in the k-loop; and
-compiler-owned accumulators that fill the accumulator file exactly were spilled at every loop header.
-Why 16x16x32: the chip is POWER-bound on this kernel (1.42 GHz of 2.4 at 8192^3, profiles/r6_w4_v1_experiments.txt): the same instruction
-stream on v_mfma_f32_16x16x32_bf16 ran 7 % faster than on 32x32x16 (half the accumulator-file traffic per flop).
+    v[96:127]   A fragments of k-step 1: FA[1][i] = v[96 + 4 i : +3]      } dead while an epilogue runs (re-read before their next use):
+    v[128:159]  B fragments of k-step 1: FB[1][j] = v[128 + 4 j : +3]     } hipcc may spread into v[96:143] there (amdgpu_num_vgpr(144))
+    v[160:191]  A fragments of k-step 0: FA[0][i]                         } live across an epilogue: the next tile's first k-step is read
+    v[192:223]  B fragments of k-step 0: FB[0][j]                         } during the finished tile's last k-tile
+    v[224:255]  unused
+    v[0:95]     hipcc's across the k-loop (addresses, loop state): every k-loop statement clobbers v[96:255] and m0, so nothing of the
+                compiler's lives there across one; scripts/check_w4_asm.py audits that no compiler instruction names v144+ or an accumulator.
+Why asm: handed the same stream as C++, hipcc gave every re-load of a fragment register a fresh physical register, ran out of registers and
+spilled behind a vmcnt(0) in the k-loop; compiler-owned accumulators that fill the accumulator file exactly were spilled at every loop header.
 
-One k-tile (64 deep) = 4 halves of 32 MFMAs, fillers spread evenly over the gaps between MFMAs (16 cycles each):
-    H0 (k-step 0, j 0..3): 4 B reads (k-step 0, j 4..7);                pieces 0..5:  [s_waitcnt vmcnt(15)] ds_write_b128 | buffer_load
-    H1 (k-step 0, j 4..7): 4 B reads (k-step 1, j 0..3), 8 A reads (k-step 1); pieces 6..9
-    H2 (k-step 1, j 0..3): 4 B reads (k-step 1, j 4..7);                pieces 10..15
-    s_waitcnt lgkmcnt(0); s_barrier
-    H3 (k-step 1, j 4..7): 8 A reads + 4 B reads of the NEXT k-tile's k-step 0 (other buffer)
-Waits (issue order = text order): vmcnt(15) in front of every LDS write -- the piece was loaded one k-tile ago and exactly 15 loads are
-younger; the first k-tile of an output tile (FRESH) needs none: the epilogue in front of it has waited for every load (so that its own
-stores never stand between a load and its wait).  lgkmcnt(W) in front of a half, W = LDS writes issued behind the reads it needs (LDS
-operations retire in order).
+LDS image: rows of 128 bytes, 16-byte chunk index ^ ((row >> 1) & 7) (K-strided B: [64 k][32 chunks], chunk ^ swz(k)).  A DMA instruction
+writes LANE-LINEARLY, so the swizzle is applied on the GLOBAL side: the lane that sits at physical chunk p of row r fetches logical chunk
+p ^ swz(r) (W4Addr::aofs / bofs, gemm_w4.hip); the fragment reads see the image they always saw.  Piece x (4 KiB = 32 rows, or 8 k-rows of a
+K-strided B) of an operand: wave w writes its 1 KiB at M0 = ad.ldsw + buffer + 4096 x.
 
-python scripts/gen_w4_acc.py [out.inc] [experiment flags] rewrites the file."""
+One k-tile t (64 deep, buffer BUF = t % 2) = the 64 MFMAs of k-step 0, then the 64 of k-step 1 (for i: for j), cut at CUT1 = 16 and CUT2 = 112:
+    [0, CUT1)      fillers: the 16 fragment reads of k-step 1 from BUF.                        s_waitcnt lgkmcnt(0); s_barrier
+                   -> every wave holds all of k-tile t in registers: BUF is free
+    [CUT1, CUT2)   fillers: the 16 DMA loads of k-tile t + 2 into BUF, the M0 write and its load in different MFMA gaps (the MFMA between
+                   them is the wait state the M0 write needs).                                 s_waitcnt vmcnt(16); s_barrier
+                   -> the 16 loads of k-tile t + 1, issued one k-tile ago into BUF ^ 1, have landed in every wave (loads return in order)
+    [CUT2, 128)    fillers: the fragment reads of k-tile t + 1's k-step 0 from BUF ^ 1 (the k-step-0 registers are free since MFMA 64).
+The next k-tile starts with s_waitcnt lgkmcnt(0).  FRESH (first k-tile of an output tile): k-step 0 takes C = 0 and the middle part waits
+for no load -- the epilogue in front of it has waited for every load (its own stores never stand between a load and its wait).
+gemm_w4.hip calls the three parts w4_h0 / w4_h1 / w4_h2 (w4_h3 is empty: the register-staged form had four).
+
+python scripts/gen_w4_acc.py [out.inc] [c1=<n>] [c2=<n>] rewrites the file (scripts/build_w4_variant.sh builds A/B libraries)."""
 import os
 import sys
 
-# experiment switches (scripts/build_w4_variant.sh): python scripts/gen_w4_acc.py <out.inc> flag ...
-FLAGS = set(sys.argv[2:])
+FLAGS = [a for a in sys.argv[2:]]
 OUT = sys.argv[1] if len(sys.argv) > 1 else None
-
 V0 = 96
-# A set 1 and B slot 1 are DEAD while the epilogue runs (re-read in H0 / H1 before their next use): they sit lowest, right above hipcc's
-# registers, so that a compiler that overruns its budget in an epilogue (it does: amdgpu_num_vgpr is not a hard limit) lands in them
-FA_BASE = {1: 96, 0: 208}
-FB_BASE = {1: 128, 0: 240}
-ST = lambda x: f"v[{144 + 4 * x}:{147 + 4 * x}]"
+FA_BASE = {1: 96, 0: 160}
+FB_BASE = {1: 128, 0: 192}
 FA = lambda s, i: f"v[{FA_BASE[s] + 4 * i}:{FA_BASE[s] + 4 * i + 3}]"
-FB = lambda s, q: f"v[{FB_BASE[s] + 4 * q}:{FB_BASE[s] + 4 * q + 3}]"
+FB = lambda s, j: f"v[{FB_BASE[s] + 4 * j}:{FB_BASE[s] + 4 * j + 3}]"
 ACC = lambda i, j: f"a[{4 * (8 * i + j)}:{4 * (8 * i + j) + 3}]"
 BUF = 32768          # bytes of one operand of one k-tile buffer
+BREG = 65536         # B buffers start here
 FRAG = 2048          # bytes of 16 rows of a buffer
-CLOB = ", ".join([f'"a{r}"' for r in range(256)] + [f'"v{r}"' for r in range(V0, 256)] + ['"memory"'])
+CLOB = ", ".join([f'"a{r}"' for r in range(256)] + [f'"v{r}"' for r in range(V0, 256)] + ['"m0"', '"memory"'])
 
 
-def mfmas(h, slot, aset, fresh):
-    """the 32 MFMAs of half h (column fragments 4 h + q): for i: for q"""
+def mfmas(ks, fresh):
+    """the 64 MFMAs of k-step ks: for i: for j"""
     out = []
     for i in range(8):
-        for q in range(4):
-            acc = ACC(i, 4 * h + q)
-            out.append(f"v_mfma_f32_16x16x32_bf16 {acc}, {FB(slot, q)}, {FA(aset, i)}, {'0' if fresh else acc}")
+        for j in range(8):
+            acc = ACC(i, j)
+            out.append(f"v_mfma_f32_16x16x32_bf16 {acc}, {FB(ks, j)}, {FA(ks, i)}, {'0' if fresh else acc}")
     return out
 
 
 class Ops:
-    """operand list of one asm statement: name -> %n, in first-use order"""
-
     def __init__(self):
         self.names, self.cons = [], []
 
@@ -80,56 +79,43 @@ class Ops:
         return ", ".join(f'"{c}"({n})' for c, n in zip(self.cons, self.names))
 
 
-def reads_a(o, aset, ks, buf):
-    """A is always K-contiguous: fragment i = 16 rows, one ds_read_b128; the k-step is in the address register (XOR swizzle)"""
-    return [] if "noread" in FLAGS else [f"ds_read_b128 {FA(aset, i)}, {o(f'ad.adA[{ks}]')} offset:{buf * BUF + i * FRAG}" for i in range(8)]
+def reads(o, bkc, ks, buf):
+    """all fragment reads of k-step ks from buffer buf: A 0 first (the first MFMA row needs A 0 and every B), then B 0..7, then A 1..7"""
+    ra = [f"ds_read_b128 {FA(ks, i)}, {o(f'ad.adA[{ks}]')} offset:{buf * BUF + i * FRAG}" for i in range(8)]
+    rb = []
+    for j in range(8):
+        if bkc:
+            rb.append(f"ds_read_b128 {FB(ks, j)}, {o(f'ad.adB[{ks}]')} offset:{buf * BUF + j * FRAG}")
+        else:
+            lo = FB_BASE[ks] + 4 * j
+            ad = o(f"ad.adB[{j}]")
+            rb.append([f"ds_read_b64_tr_b16 v[{lo}:{lo + 1}], {ad} offset:{buf * BUF + ks * 16384}",
+                       f"ds_read_b64_tr_b16 v[{lo + 2}:{lo + 3}], {ad} offset:{buf * BUF + ks * 16384 + 2048}"])
+    return [ra[0]] + rb + ra[1:]
 
 
-def reads_b(o, bkc, slot, ks, h, buf):
-    """B fragments j = 4 h + q of k-step ks.  K-contiguous: as A.  K-strided: image [64 k][32 chunks] (chunk ^ swz(k)), one address register per
-    j, the k-step (32 k-rows = 16 KiB) in the offset; a fragment is two transposing 8-byte reads (k + 0..3, k + 4..7: 4 k-rows = 2 KiB apart)"""
-    if "noread" in FLAGS:
-        return []
-    if bkc:
-        return [f"ds_read_b128 {FB(slot, q)}, {o(f'ad.adB[{ks}]')} offset:{buf * BUF + (4 * h + q) * FRAG}" for q in range(4)]
-    out = []
-    for q in range(4):
-        lo = FB_BASE[slot] + 4 * q
-        ad = o(f"ad.adB[{4 * h + q}]")
-        out.append(f"ds_read_b64_tr_b16 v[{lo}:{lo + 1}], {ad} offset:{buf * BUF + ks * 16384}")
-        out.append(f"ds_read_b64_tr_b16 v[{lo + 2}:{lo + 3}], {ad} offset:{buf * BUF + ks * 16384 + 2048}")
-    return out
-
-
-def wl(o, bkc, x, buf, nowait):
-    """piece x: [vmcnt] LDS write of the staged piece (k-tile t + 1) into buffer buf, then its re-load with k-tile t + 2"""
-    out = []
+def dma(o, x, buf, ka="koffA", kb="koffB"):
+    """piece x (0..7: A, 8..15: B) of the cursor's k-tile -> buffer buf: 1 KiB per wave at M0 = this wave's 1 KiB of the piece's 4 KiB"""
     if x < 8:
-        wr, ofs, rsrc, koff = o("ad.wrA"), o(f"ad.aofs[{x}]"), o("rA", "s"), o("koffA", "s")
+        ofs, rsrc, koff, base = o(f"ad.aofs[{x}]"), o("rA", "s"), o(ka, "s"), buf * BUF + x * 4096
     else:
-        wr = o("ad.wrB[0]") if bkc else o(f"ad.wrB[{x & 1}]")     # K-strided B: the swizzle of a piece's k-rows depends on its parity
-        ofs, rsrc, koff = o(f"ad.bofs[{x - 8}]"), o("rB", "s"), o("koffB", "s")
-    if "nowrite" not in FLAGS:
-        w = f"ds_write_b128 {wr}, {ST(x)} offset:{buf * BUF + (x & 7) * 4096}"
-        out.append(w if (nowait or "nowait" in FLAGS) else ["s_waitcnt vmcnt(15)", w])
-    if "noload" not in FLAGS:
-        out.append(f"buffer_load_dwordx4 {ST(x)}, {ofs}, {rsrc}, {koff} offen")
-    return out
+        ofs, rsrc, koff, base = o(f"ad.bofs[{x - 8}]"), o("rB", "s"), o(kb, "s"), BREG + buf * BUF + (x - 8) * 4096
+    return [f"s_add_u32 m0, {o('ad.ldsw', 's')}, {base}", f"buffer_load_dwordx4 {ofs}, {rsrc}, {koff} offen lds"]
 
 
-def half(h, slot, aset, fresh, fillers, head):
-    """32 MFMAs with the fillers spread evenly over the gaps behind them"""
-    lines = [x for x in head if not ("nobarrier" in FLAGS and x == "s_barrier")]
-    mm = mfmas(h, slot, aset, fresh)
+def part(mm, fillers, head, tail, span=None):
+    """MFMAs mm with the fillers spread evenly over the gaps behind the first `span` of them"""
+    lines = list(head)
+    span = span or len(mm)
     n = len(fillers)
     at = {}
     for k, f in enumerate(fillers):
-        at.setdefault((k * 32) // n if n else 0, []).append(f)
+        at.setdefault((k * span) // n if n else 0, []).append(f)
     for g, m in enumerate(mm):
         lines.append(m)
         for f in at.get(g, []):
             lines.extend(f if isinstance(f, list) else [f])
-    return lines
+    return lines + list(tail)
 
 
 def emit(lines):
@@ -139,10 +125,6 @@ def emit(lines):
     return '"' + "\\n\\t".join(flat) + '"'
 
 
-def nwrites(fill):
-    return sum(1 for f in fill for l in (f if isinstance(f, list) else [f]) if l.startswith("ds_write"))
-
-
 def variants(out, conds_texts):
     for n, (cond, txt, ops) in enumerate(conds_texts):
         kw = ("if constexpr (" + cond + ")") if n == 0 else ("else if constexpr (" + cond + ")" if n + 1 < len(conds_texts) else "else")
@@ -150,10 +132,11 @@ def variants(out, conds_texts):
 
 
 SIG = "const W4Addr& ad, const u32x4& rA, const u32x4& rB, int koffA, int koffB"
-out = ["// GENERATED by scripts/gen_w4_acc.py -- do not edit (register plan and schedule: the generator's docstring).",
-       "// BKC = 1: B K-contiguous (nn.Linear forward); BKC = 0: B K-strided (dgrads, the [E, in, out] expert weights).", ""]
+out = ["// GENERATED by scripts/gen_w4_dma.py -- do not edit (register plan and schedule: the generator's docstring).",
+       "// BKC = 1: B K-contiguous (nn.Linear forward); BKC = 0: B K-strided (dgrads, the [E, in, out] expert weights).",
+       ""]
 
-# ---- prologue: k-tile 0 -> buffer 0, k-tile 1 -> staging registers, all of it landed (the first k-tile is a FRESH one: no vmcnt waits)
+# ---- prologue: k-tile 0 -> buffer 0, k-tile 1 -> buffer 1; k-tile 0 landed
 out.append("template <int BKC>")
 out.append(f"__device__ __forceinline__ void w4_prologue({SIG}, int koffA1, int koffB1) {{")
 cs = []
@@ -161,80 +144,78 @@ for bkc in (1, 0):
     o = Ops()
     pro = []
     for x in range(16):
-        pro.append(f"buffer_load_dwordx4 {ST(x)}, {o(f'ad.aofs[{x}]') if x < 8 else o(f'ad.bofs[{x - 8}]')}, {o('rA', 's') if x < 8 else o('rB', 's')}, {o('koffA', 's') if x < 8 else o('koffB', 's')} offen")
+        d = dma(o, x, 0)
+        pro += [d[0], "s_nop 0", d[1]]           # (M0 write -> LDS-DMA: one wait state; in the loop an MFMA stands between them)
     for x in range(16):
-        wr = o("ad.wrA") if x < 8 else (o("ad.wrB[0]") if bkc else o(f"ad.wrB[{x & 1}]"))
-        pro.append(["s_waitcnt vmcnt(15)", f"ds_write_b128 {wr}, {ST(x)} offset:{(x & 7) * 4096}"])
-        pro.append(f"buffer_load_dwordx4 {ST(x)}, {o(f'ad.aofs[{x}]') if x < 8 else o(f'ad.bofs[{x - 8}]')}, {o('rA', 's') if x < 8 else o('rB', 's')}, {o('koffA1', 's') if x < 8 else o('koffB1', 's')} offen")
-    pro.append("s_waitcnt vmcnt(0)")
+        d = dma(o, x, 1, "koffA1", "koffB1")
+        pro += [d[0], "s_nop 0", d[1]]
+    pro += ["s_waitcnt vmcnt(16)"]
     cs.append((f"BKC == {bkc}", emit(pro), o.text()))
 variants(out, cs)
 out.append("}")
-out.append("// the barrier that publishes buffer 0, then the fragment reads of its k-step 0 (A set 0, B slot 0)")
+out.append("// the barrier that publishes buffer 0, then the fragment reads of its k-step 0")
 out.append("template <int BKC>")
 out.append("__device__ __forceinline__ void w4_first_reads(const W4Addr& ad) {")
 cs = []
 for bkc in (1, 0):
     o = Ops()
-    cs.append((f"BKC == {bkc}", emit(["s_waitcnt lgkmcnt(0)", "s_barrier"] + reads_a(o, 0, 0, 0) + reads_b(o, bkc, 0, 0, 0, 0)), o.text()))
+    cs.append((f"BKC == {bkc}", emit(["s_barrier"] + reads(o, bkc, 0, 0)), o.text()))
 variants(out, cs)
 out.append("}")
 out.append("")
 
 
-def gen_half(name, second_flag, build):
-    """build(o, bkc, b, flag) -> (h, slot, aset, fresh, fillers, head-without-lgkm, lgkm-count or None)"""
-    out.append(f"template <int BKC, int BUFI, bool {second_flag}>")
+def gen(name, flagname, build):
+    out.append(f"template <int BKC, int BUFI, bool {flagname}>")
     out.append(f"__device__ __forceinline__ void {name}({SIG}) {{")
     cs = []
     for bkc in (1, 0):
         for b in range(2):
             for flag in (True, False):
                 o = Ops()
-                h, slot, aset, fresh, fill, head = build(o, bkc, b, flag)
-                cs.append((f"BKC == {bkc} && BUFI == {b} && {second_flag if flag else '!' + second_flag}", emit(half(h, slot, aset, fresh, fill, head)), o.text()))
+                cs.append((f"BKC == {bkc} && BUFI == {b} && {flagname if flag else '!' + flagname}", emit(build(o, bkc, b, flag)), o.text()))
     variants(out, cs)
     out.append("}")
 
 
-# ---- H0: k-step 0, j 0..3 (slot 0, A set 0); reads B (k-step 0, j 4..7) -> slot 1; pieces 0..5 (A)
-def h0(o, bkc, b, fresh):
-    fill = reads_b(o, bkc, 1, 0, 1, b)
-    for x in range(6):
-        fill += wl(o, bkc, x, b ^ 1, fresh)
-    return 0, 0, 0, fresh, fill, ["s_waitcnt lgkmcnt(0)"]
+# MFMA stream of one k-tile: 64 of k-step 0 then 64 of k-step 1, cut at CUT1 and CUT2 (flags c1=, c2=):
+#   [0, CUT1)      fillers: the 16 fragment reads of k-step 1 from BUF;   then lgkmcnt(0) + barrier -> BUF is free
+#   [CUT1, CUT2)   fillers: the 16 DMA loads of the cursor's k-tile into BUF; then vmcnt(16) + barrier -> k-tile t + 1 has landed
+#   [CUT2, 128)    fillers: the fragment reads of k-tile t + 1's k-step 0 from BUF ^ 1 (CUT2 >= 64: the sets 0 are free)
+CUT1, CUT2 = 16, 112
+for f in FLAGS:
+    if f.startswith("c1="):
+        CUT1 = int(f[3:])
+    if f.startswith("c2="):
+        CUT2 = int(f[3:])
+assert 0 < CUT1 <= 64 <= CUT2 < 128
 
 
-# ---- H1: k-step 0, j 4..7 (slot 1, A set 0); reads B (k-step 1, j 0..3) -> slot 0, A (k-step 1) -> set 1; pieces 6..9
-def h1(o, bkc, b, fresh):
-    fill = reads_b(o, bkc, 0, 1, 0, b) + reads_a(o, 1, 1, b)
-    for x in range(6, 10):
-        fill += wl(o, bkc, x, b ^ 1, fresh)
-    return 1, 1, 0, fresh, fill, [f"s_waitcnt lgkmcnt({0 if 'nowrite' in FLAGS else 6})"]     # H0's 6 writes follow the reads H1 needs
+def stream(fresh):
+    return mfmas(0, fresh) + mfmas(1, False)
 
 
-# ---- H2: k-step 1, j 0..3 (slot 0, A set 1); reads B (k-step 1, j 4..7) -> slot 1; pieces 10..15
-def h2(o, bkc, b, nowait):
-    fill = reads_b(o, bkc, 1, 1, 1, b)
-    for x in range(10, 16):
-        fill += wl(o, bkc, x, b ^ 1, nowait)
-    return 0, 0, 1, False, fill, [f"s_waitcnt lgkmcnt({0 if 'nowrite' in FLAGS else 4})"]     # H1's 4 writes follow its reads
+def p1(o, bkc, b, fresh):
+    return part(stream(fresh)[:CUT1], reads(o, bkc, 1, b), ["s_waitcnt lgkmcnt(0)"], ["s_waitcnt lgkmcnt(0)", "s_barrier"])
 
 
-gen_half("w4_h0", "FRESH", h0)
-gen_half("w4_h1", "FRESH", h1)
-gen_half("w4_h2", "NOWAIT", h2)
-# ---- barrier + H3: k-step 1, j 4..7 (slot 1, A set 1); reads the NEXT k-tile's k-step 0 (other buffer): A -> set 0, B (j 0..3) -> slot 0
+def p2(o, bkc, b, fresh):
+    fill = []
+    for x in range(16):
+        fill += dma(o, x, b)             # M0 write and its load in different MFMA gaps (the MFMA between them is the wait state)
+    return part(stream(fresh)[CUT1:CUT2], fill, [], ([] if fresh else ["s_waitcnt vmcnt(16)"]) + ["s_barrier"])
+
+
+def p3(o, bkc, b, unused):
+    mm = stream(False)[CUT2:]
+    return part(mm, reads(o, bkc, 0, b ^ 1), [], [], span=max(len(mm) - 6, 1))
+
+
+gen("w4_h0", "FRESH", p1)
+gen("w4_h1", "FRESH", p2)
+gen("w4_h2", "NOWAIT", p3)
 out.append("template <int BKC, int BUFI>")
-out.append("__device__ __forceinline__ void w4_h3(const W4Addr& ad) {")
-cs = []
-for bkc in (1, 0):
-    for b in range(2):
-        o = Ops()
-        fill = reads_a(o, 0, 0, b ^ 1) + reads_b(o, bkc, 0, 0, 0, b ^ 1)
-        cs.append((f"BKC == {bkc} && BUFI == {b}", emit(half(1, 1, 1, False, fill, ["s_waitcnt lgkmcnt(0)", "s_barrier"])), o.text()))
-variants(out, cs)
-out.append("}")
+out.append("__device__ __forceinline__ void w4_h3(const W4Addr&) {}      // (the LDS-DMA schedule has three parts)")
 out.append("")
 out.append("// Accumulator blocks (I, 4 JH + q), q = 0..3, as fp32: r[4 q + e] = row 16 I + lane % 16, column 16 (4 JH + q) + 4 (lane / 16) + e of the wave tile.")
 out.append("// The caller has put the MFMA -> accumulator-read wait states in front.")
