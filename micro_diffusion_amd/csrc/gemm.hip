@@ -608,9 +608,13 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     const md_gemm_args* a = &a_copy;
     if (a->problems) {            // grouped launch: pp256 or nothing; A / B / M / N / leading dimensions come from the problem table
         if (!a->C || a->K <= 0 || a->ksplit <= 0 || a->mode != MD_EPI_STORE_F32 || a->sSplit <= 0 || !md_gemm_pp_eligible(a)) return MD_BAD_ARG;
-        if (a->variant != MD_GEMM_AUTO && a->variant != MD_GEMM_PP256) return MD_NOT_ELIGIBLE;
-        if (a->chosen_variant) *a->chosen_variant = MD_GEMM_PP256;
-        return md_gemm_pp_launch(a, stream);
+        if (a->variant != MD_GEMM_AUTO && a->variant != MD_GEMM_PP256 && a->variant != MD_GEMM_W4) return MD_NOT_ELIGIBLE;
+        if (a->variant == MD_GEMM_W4 && !md_gemm_w4_eligible(a)) return MD_NOT_ELIGIBLE;
+        // the 4-wave kernel takes the grouped weight gradients it covers (whole interior tiles) on a free chip (profiles/r6_w4_wgrad.txt)
+        const bool w4 = a->variant == MD_GEMM_W4 || (a->variant == MD_GEMM_AUTO && md_gemm_w4_eligible(a) && !(a->cu_limit > 0 && a->cu_limit < 256) &&
+                                                     !getenv("MD_GEMM_NO_W4") && !getenv("MD_GEMM_NO_W4_TN"));
+        if (a->chosen_variant) *a->chosen_variant = w4 ? MD_GEMM_W4 : MD_GEMM_PP256;
+        return w4 ? md_gemm_w4_launch(a, stream) : md_gemm_pp_launch(a, stream);
     }
     if (!a->A || !a->B || !a->C) return MD_BAD_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->ksplit <= 0) return MD_BAD_ARG;
@@ -656,7 +660,8 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
         // at least 192 tiles and no CU hold (profiles/r6_w4_vs_pp256.txt); the md_gemm_args.cu_limit launches of the
         // data-parallel step keep PP256 and its split-K tail
         const char* w4min = getenv("MD_GEMM_W4_MIN_TILES");            // (A/B runs; default: the launches PP256 used to take)
-        if (md_gemm_w4_eligible(a) && tiles256 >= (w4min ? atoi(w4min) : 192) && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4"))
+        if (md_gemm_w4_eligible(a) && tiles256 >= (w4min ? atoi(w4min) : 192) && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4") &&
+            (a->a_kcontig || !getenv("MD_GEMM_NO_W4_TN")))
             variant = MD_GEMM_W4;
         else if (md_gemm_pp_eligible(a) && tiles256 >= 192)
             variant = MD_GEMM_PP256;

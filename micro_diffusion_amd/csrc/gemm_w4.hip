@@ -36,7 +36,8 @@ namespace {
 
 // Per-lane addresses the generated k-loop takes as asm operands (all in hipcc's registers).
 struct W4Addr {
-    unsigned adA[2];     // A fragment reads: [k-step]; row lane % 16 (+ 16 i: immediate), 16-byte chunk (4 ks + lane / 16) ^ swizzle
+    unsigned adA[8];     // A K-contiguous: fragment reads [k-step] ([2..7] unused): row lane % 16 (+ 16 i: immediate), 16-byte chunk (4 ks + lane / 16) ^ swizzle.
+                         // A K-strided (weight gradients): [row fragment i], as B K-strided
     unsigned adB[8];     // B K-contiguous: [k-step] as A ([2..7] unused).  B K-strided: [column fragment j], the k-step is an immediate
     unsigned aofs[8], bofs[8];   // global byte offsets of this thread's 8 pieces of each operand, relative to the tile's descriptor
     unsigned ldsw;       // LDS address of this wave's 1 KiB inside a 4 KiB piece (M0 of its DMA loads = ldsw + buffer + 4096 x: immediates)
@@ -308,11 +309,31 @@ __device__ __forceinline__ void w4_epilogue(const md_gemm_args& p, const PPPlan&
 #undef W4_EPI_STEP
 }
 
+// fp32 slice epilogue (weight gradients: split-K slices for md_splitk_reduce; interior tiles only).  A lane owns 4 consecutive columns of a
+// row per 16 x 16 block: stored as they are, 16 bytes per lane -- a store instruction writes 16 rows x 64 contiguous bytes.
+__device__ __forceinline__ void w4_epilogue_f32(float* tile, int64_t ldc, int wrow, int wcol, int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    float* const p0 = tile + (int64_t)(wrow + (lane & 15)) * ldc + wcol + 4 * (lane >> 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no store between a DMA load and its wait (gen_w4_acc.py, FRESH)
+#define W4_F32_STEP(I, JH)                                                                                               \
+    {                                                                                                                    \
+        float a[16];                                                                                                     \
+        w4_acc_read16<I, JH>(a);                                                                                         \
+        float* const pr = p0 + (int64_t)(16 * (I)) * ldc + 64 * (JH);                                                    \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                    \
+            *reinterpret_cast<float4*>(pr + 16 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);   \
+    }
+    W4_F32_STEP(0, 0) W4_F32_STEP(0, 1) W4_F32_STEP(1, 0) W4_F32_STEP(1, 1) W4_F32_STEP(2, 0) W4_F32_STEP(2, 1) W4_F32_STEP(3, 0) W4_F32_STEP(3, 1)
+    W4_F32_STEP(4, 0) W4_F32_STEP(4, 1) W4_F32_STEP(5, 0) W4_F32_STEP(5, 1) W4_F32_STEP(6, 0) W4_F32_STEP(6, 1) W4_F32_STEP(7, 0) W4_F32_STEP(7, 1)
+#undef W4_F32_STEP
+}
+
 // amdgpu_num_vgpr(144): hipcc's values that live across the k-loop are below v96 by construction (every k-loop statement clobbers
 // v[96:255]); inside an epilogue it may use v[96:143], which hold nothing then (gen_w4_acc.py register plan).  A budget of 96 was
 // overrun -- not spilled -- by the instantiations with the heaviest epilogues (v96 / v97 handed out as temporaries: registers the k-loop
 // owns).  scripts/check_w4_asm.py (tests/test_build_static.py) audits every build for v144+ / accumulator use.
-template <int BKC, int EPI>
+template <int AKC, int BKC, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gemm_bf16_w4_kernel(md_gemm_args p, PPPlan w) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W4_BREG + 4 * W4_SLAB];   // 160 KiB: the whole LDS of a CU
     const int tid = threadIdx.x, lane = tid & 63;
@@ -341,8 +362,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
         const int ra = wr * 128 + (lane & 15), rb = wc * 128 + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            ad.adA[ks] = lds0 + (unsigned)(ra * 128 + ((((4 * ks + (lane >> 4)) ^ (ra >> 1)) & 7) << 4));
+            if (AKC) ad.adA[ks] = lds0 + (unsigned)(ra * 128 + ((((4 * ks + (lane >> 4)) ^ (ra >> 1)) & 7) << 4));
             if (BKC) ad.adB[ks] = lds0 + (unsigned)(W4_BREG + rb * 128 + ((((4 * ks + (lane >> 4)) ^ (rb >> 1)) & 7) << 4));
+        }
+        if (AKC) {
+#pragma unroll
+            for (int i = 2; i < 8; ++i) ad.adA[i] = 0;
+        } else {                                   // K-strided A image: as the K-strided B image below, rows <-> this wave's 128 output rows
+            const int li = lane & 15, g = lane >> 4;
+            const int kk = 8 * g + (li >> 2);
+            const int swz = ((kk & 3) << 1) | (((kk >> 3) & 1) << 3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = wr * 128 + 16 * i + 4 * (li & 3);
+                ad.adA[i] = lds0 + (unsigned)(kk * 512 + ((((col >> 3) ^ swz) & 31) << 4) + ((col >> 2) & 1) * 8);
+            }
         }
         if (!BKC) {
             // K-strided B image: [64 k-rows][32 chunks of 16 B], physical chunk = chunk ^ swz(k), swz(k) = (k & 3) << 1 | ((k >> 3) & 1) << 3
@@ -369,18 +403,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
     // ---- load cursor: runs two k-tiles (one pair) ahead of the multiplications, across tile boundaries.  nk is even, so the
     // cursor changes tiles only at the bottom of the pair loop; inside a k-tile it only steps its scalar byte offset.
     int s_n = 0, s_kt = 0, s_koffA = 0, s_koffB = 0;
-    const int kstepB = BKC ? BKT * 2 : BKT * w.ldb * 2;       // bytes per k-tile of the B tile (K-strided: 64 rows of ldb elements)
+    int kstepA = AKC ? BKT * 2 : BKT * w.lda * 2;             // bytes per k-tile of the cursor's A / B tile (K-strided: 64 rows of ld elements;
+    int kstepB = BKC ? BKT * 2 : BKT * w.ldb * 2;             // a grouped launch takes the leading dimensions of the tile's problem)
+    constexpr bool GROUPABLE = !AKC && !BKC && EPI == PP_E_F32;
     u32x4 rA, rB;                                  // wave-uniform buffer descriptors of the cursor's A / B tile (first k element of its split)
     auto stager_open = [&](int n) {
         int m0, n0, batch, split;
+        if (GROUPABLE && w.nprob) {                // grouped launch (the weight gradients of one DiT block): the item's problem supplies operands,
+            int q;                                 // extents and leading dimensions (interior tiles only: md_gemm_w4_eligible)
+            work_decode_grouped(w, w_first + n * w_stride, q, m0, n0, split);
+            const PPProblem& pr = w.prob[q];
+            const int sw = (tid >> 5) & 3;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int c8 = ((tid & 31) ^ ((sw << 1) | ((x & 1) << 3))) * 8;
+                const int kr = x * 8 + (tid >> 5);
+                ad.aofs[x] = (unsigned)(kr * pr.lda + c8) * 2u;
+                ad.bofs[x] = (unsigned)(kr * pr.ldb + c8) * 2u;
+            }
+            kstepA = BKT * pr.lda * 2;
+            kstepB = BKT * pr.ldb * 2;
+            const int64_t kb = (int64_t)split * w.kspan;
+            const uint64_t ua = (uint64_t)(uintptr_t)(reinterpret_cast<const bf16*>(pr.A) + kb * pr.lda + m0);
+            const uint64_t ub = (uint64_t)(uintptr_t)(reinterpret_cast<const bf16*>(pr.B) + kb * pr.ldb + n0);
+            rA = u32x4{(unsigned)ua, (unsigned)(ua >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+            rB = u32x4{(unsigned)ub, (unsigned)(ub >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+            s_koffA = 0;
+            s_koffB = 0;
+            return;
+        }
         work_decode(w, w_first + n * w_stride, m0, n0, batch, split);
         const int c = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;   // a DMA lane sits at PHYSICAL chunk tid % 8 of its row: it fetches the logical chunk the swizzle puts there
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int row = x * 32 + (tid >> 3);
-            int ga = m0 + row;
-            ga = (ga < w.M ? ga : w.M - 1) - m0;
-            ad.aofs[x] = (unsigned)(ga * w.lda + c) * 2u;
+            if (AKC) {
+                int ga = m0 + row;
+                ga = (ga < w.M ? ga : w.M - 1) - m0;
+                ad.aofs[x] = (unsigned)(ga * w.lda + c) * 2u;
+            } else {                                       // K-strided A: as the K-strided B below (rows <-> the tile's 256 output rows)
+                int gc = m0 + ((tid & 31) ^ ((((tid >> 5) & 3) << 1) | ((x & 1) << 3))) * 8;
+                const int last = (w.M - 1) & ~7;
+                gc = (gc < last ? gc : last) - m0;
+                ad.aofs[x] = (unsigned)((x * 8 + (tid >> 5)) * w.lda + gc) * 2u;
+            }
             if (BKC) {
                 int gb = n0 + row;
                 gb = (gb < w.N ? gb : w.N - 1) - n0;
@@ -393,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
             }
         }
         const int64_t kbeg = (int64_t)split * w.kspan;
-        const bf16* pa = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA + (int64_t)m0 * w.lda + kbeg;
+        const bf16* pa = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA + (AKC ? (int64_t)m0 * w.lda + kbeg : kbeg * w.lda + m0);
         const bf16* pb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB + (BKC ? (int64_t)n0 * w.ldb + kbeg : kbeg * w.ldb + n0);
         // raw buffer: 48-bit base, stride 0, no bounds (rows are clamped above), DATA_FORMAT = 32 bits (0x00020000)
         const uint64_t ua = (uint64_t)(uintptr_t)pa, ub = (uint64_t)(uintptr_t)pb;
@@ -413,11 +479,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
     // ---- the k-loop is generated inline asm on literal registers (gemm_w4_acc.inc, scripts/gen_w4_acc.py).
     // prologue: k-tile 0 into buffer 0 (landed), k-tile 1 into buffer 1 (in flight), fragments of k-tile 0's k-step 0
     stager_open(0);
-    w4_prologue<BKC>(ad, rA, rB, 0, 0, BKT * 2, kstepB);
-    s_koffA = 2 * BKT * 2;
+    w4_prologue<AKC, BKC>(ad, rA, rB, 0, 0, kstepA, kstepB);
+    s_koffA = 2 * kstepA;
     s_koffB = 2 * kstepB;
     stager_pair_done();
-    w4_first_reads<BKC>(ad);
+    w4_first_reads<AKC, BKC>(ad);
 
     int c_n = 0, c_kt = 0;
     // One k-tile (scripts/gen_w4_acc.py): entering, the k-step-0 registers hold this k-tile's first fragments (buffer BUF; the reads possibly
@@ -426,12 +492,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
     // + the next k-tile's first fragments.  FRESH = first k-tile of an output tile.
 #define W4_KTILE(BUF, FRESH)                                                                                            \
     do {                                                                                                                \
-        w4_h0<BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                           \
-        w4_h1<BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                           \
-        w4_h2<BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                           \
-        s_koffA += BKT * 2;                                                                                             \
+        w4_h0<AKC, BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                      \
+        w4_h1<AKC, BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                      \
+        w4_h2<AKC, BKC, BUF, FRESH>(ad, rA, rB, s_koffA, s_koffB);                                                      \
+        s_koffA += kstepA;                                                                                              \
         s_koffB += kstepB;                                                                                              \
-        w4_h3<BKC, BUF>(ad);                                                                                            \
+        w4_h3<AKC, BKC, BUF>(ad);                                                                                       \
     } while (0)
 
     for (int it = 0; it < pairs; ++it) {
@@ -442,6 +508,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
         c_kt += 2;
         if (c_kt == w.nk) {
             // ---- epilogue of the finished tile (the loads of the next tile's first two k-tiles are in flight / in LDS)
+            if constexpr (EPI == PP_E_F32) {
+                int m0, n0, batch = 0, split;
+                float* tile;
+                int64_t ldc;
+                if (GROUPABLE && w.nprob) {                // dense rows of the problem's N inside the slice, at its c_off
+                    int q;
+                    work_decode_grouped(w, w_first + c_n * w_stride, q, m0, n0, split);
+                    const PPProblem& pr = w.prob[q];
+                    ldc = pr.N;
+                    tile = reinterpret_cast<float*>(p.C) + (int64_t)split * p.sSplit + pr.c_off + (int64_t)m0 * ldc + n0;
+                } else {
+                    work_decode(w, w_first + c_n * w_stride, m0, n0, batch, split);
+                    ldc = p.ldc;
+                    tile = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.sC + (int64_t)split * p.sSplit + (int64_t)m0 * ldc + n0;
+                }
+                asm volatile("s_nop 15\n\ts_nop 15");      // MFMA result -> v_accvgpr_read wait states
+                w4_epilogue_f32(tile, ldc, wr * 128, wc * 128, lane);
+                c_kt = 0;
+                ++c_n;
+                continue;
+            }
             W4Tile et;
             int split;
             work_decode(w, w_first + c_n * w_stride, et.m0, et.n0, et.batch, split);
@@ -470,21 +557,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(144))) void gem
 
 }  // namespace
 
-// Instantiated: NT (nn.Linear forward) bf16 / gated residual / activation derivative; NN (dgrads, the MoE's [E, in, out] experts) bf16 /
+// Instantiated: TN (weight gradients) fp32 slices; NT (nn.Linear forward) bf16 / gated residual / activation derivative; NN (dgrads, the MoE's [E, in, out] experts) bf16 /
 // GELU(erf) with the raw copy or the cached derivative / residual / the SwiGLU backward (the w3 data gradient).
-static bool w4_instantiated(int bkc, int epi) {
+static bool w4_instantiated(int akc, int bkc, int epi) {
+    if (!akc) return !bkc && epi == PP_E_F32;                    // weight gradients: both operands K-strided, fp32 slices
     if (bkc) return epi == PP_E_BF16 || epi == PP_E_RES || epi == PP_E_DACT_GELU || epi == PP_E_DACT_MUL;
     return epi == PP_E_BF16 || epi == PP_E_BF16_GELU || epi == PP_E_BF16_GELU_D || epi == PP_E_RES || epi == PP_E_DACT_SWIGLU;
 }
 
 bool md_gemm_w4_eligible(const md_gemm_args* a) {
-    if (!a->a_kcontig) return false;
     const int epi = md_gemm_pp_epi_kind(a);
-    if (epi < 0 || !w4_instantiated(a->b_kcontig, epi)) return false;
-    if (!md_gemm_pp_shape_ok(a, epi)) return false;              // K span, N % 8, leading-dimension ranges, gate rows, interior tiles, ...
+    if (epi < 0 || !w4_instantiated(a->a_kcontig, a->b_kcontig, epi)) return false;
+    if (!md_gemm_pp_shape_ok(a, epi)) return false;              // K span, N % 8, leading-dimension ranges, gate rows, interior tiles, problem table, ...
     if (epi == PP_E_DACT_SWIGLU && (!a->aux || a->batch != 1 || a->ldaux < 2 * a->N || a->ldc < 2 * a->N)) return false;
-    if (a->ksplit != 1 || a->A_list || a->B_list || a->problems || a->timeline) return false;
+    if (a->A_list || a->B_list || a->timeline) return false;
     if (a->bias || a->alpha != 1.f) return false;                // only the plain form of every epilogue is built
+    const int64_t kspan = a->K / a->ksplit;
+    if (epi == PP_E_F32) {                                       // fp32 slices: whole interior tiles, scalar byte offsets of both K-strided cursors in 31 bits
+        if (a->ksplit > 1 && a->sSplit <= 0) return false;
+        if (a->problems) {
+            for (int i = 0; i < a->n_problems; ++i) {
+                const md_gemm_problem& s = a->problems[i];
+                if (s.M % PT || s.N % PT || kspan * (s.lda > s.ldb ? s.lda : s.ldb) >= ((int64_t)1 << 30)) return false;
+            }
+            return true;
+        }
+        if (a->M % PT || a->N % PT || a->ldc % 4) return false;
+        return kspan * (a->lda > a->ldb ? a->lda : a->ldb) < ((int64_t)1 << 30);
+    }
+    if (a->ksplit != 1 || a->problems) return false;
     if (!a->b_kcontig && (a->K * a->ldb >= (int64_t)1 << 30)) return false;   // 32-bit scalar byte offset of the K-strided cursor
     return true;
 }
@@ -497,18 +598,20 @@ int md_gemm_w4_launch(const md_gemm_args* a, hipStream_t stream) {
     if (a->tail_used) *a->tail_used = 0;
     const int epi = md_gemm_pp_epi_kind(a);
     const dim3 grid(G, 1, 1), block(256);
-#define W4_LAUNCH(BK, E) hipLaunchKernelGGL((gemm_bf16_w4_kernel<BK, E>), grid, block, 0, stream, *a, w)
-    if (a->b_kcontig) {
-        if (epi == PP_E_BF16) W4_LAUNCH(1, PP_E_BF16);
-        else if (epi == PP_E_RES) W4_LAUNCH(1, PP_E_RES);
-        else if (epi == PP_E_DACT_MUL) W4_LAUNCH(1, PP_E_DACT_MUL);
-        else W4_LAUNCH(1, PP_E_DACT_GELU);
+#define W4_LAUNCH(AK, BK, E) hipLaunchKernelGGL((gemm_bf16_w4_kernel<AK, BK, E>), grid, block, 0, stream, *a, w)
+    if (!a->a_kcontig) {
+        W4_LAUNCH(0, 0, PP_E_F32);
+    } else if (a->b_kcontig) {
+        if (epi == PP_E_BF16) W4_LAUNCH(1, 1, PP_E_BF16);
+        else if (epi == PP_E_RES) W4_LAUNCH(1, 1, PP_E_RES);
+        else if (epi == PP_E_DACT_MUL) W4_LAUNCH(1, 1, PP_E_DACT_MUL);
+        else W4_LAUNCH(1, 1, PP_E_DACT_GELU);
     } else {
-        if (epi == PP_E_BF16) W4_LAUNCH(0, PP_E_BF16);
-        else if (epi == PP_E_BF16_GELU) W4_LAUNCH(0, PP_E_BF16_GELU);
-        else if (epi == PP_E_BF16_GELU_D) W4_LAUNCH(0, PP_E_BF16_GELU_D);
-        else if (epi == PP_E_DACT_SWIGLU) W4_LAUNCH(0, PP_E_DACT_SWIGLU);
-        else W4_LAUNCH(0, PP_E_RES);
+        if (epi == PP_E_BF16) W4_LAUNCH(1, 0, PP_E_BF16);
+        else if (epi == PP_E_BF16_GELU) W4_LAUNCH(1, 0, PP_E_BF16_GELU);
+        else if (epi == PP_E_BF16_GELU_D) W4_LAUNCH(1, 0, PP_E_BF16_GELU_D);
+        else if (epi == PP_E_DACT_SWIGLU) W4_LAUNCH(1, 0, PP_E_DACT_SWIGLU);
+        else W4_LAUNCH(1, 0, PP_E_RES);
     }
 #undef W4_LAUNCH
     MD_LAUNCH_CHECK();

@@ -79,18 +79,20 @@ class Ops:
         return ", ".join(f'"{c}"({n})' for c, n in zip(self.cons, self.names))
 
 
-def reads(o, bkc, ks, buf):
-    """all fragment reads of k-step ks from buffer buf: A 0 first (the first MFMA row needs A 0 and every B), then B 0..7, then A 1..7"""
-    ra = [f"ds_read_b128 {FA(ks, i)}, {o(f'ad.adA[{ks}]')} offset:{buf * BUF + i * FRAG}" for i in range(8)]
-    rb = []
-    for j in range(8):
-        if bkc:
-            rb.append(f"ds_read_b128 {FB(ks, j)}, {o(f'ad.adB[{ks}]')} offset:{buf * BUF + j * FRAG}")
-        else:
-            lo = FB_BASE[ks] + 4 * j
-            ad = o(f"ad.adB[{j}]")
-            rb.append([f"ds_read_b64_tr_b16 v[{lo}:{lo + 1}], {ad} offset:{buf * BUF + ks * 16384}",
-                       f"ds_read_b64_tr_b16 v[{lo + 2}:{lo + 3}], {ad} offset:{buf * BUF + ks * 16384 + 2048}"])
+def reads(o, akc, bkc, ks, buf):
+    """all fragment reads of k-step ks from buffer buf: A 0 first (the first MFMA row needs A 0 and every B), then B 0..7, then A 1..7.
+    K-contiguous operand: one ds_read_b128 per 16-row fragment, the k-step in the address register (XOR swizzle).  K-strided operand (image
+    [64 k][32 chunks], chunk ^ swz(k)): one address register per fragment, the k-step (32 k-rows = 16 KiB) in the offset; a fragment is two
+    transposing 8-byte reads (k + 0..3, k + 4..7: 4 k-rows = 2 KiB apart)."""
+    def frag(kc, base_reg, which, adname, n, region):
+        if kc:
+            return f"ds_read_b128 {which(ks, n)}, {o(f'ad.{adname}[{ks}]')} offset:{buf * BUF + n * FRAG}"
+        lo = base_reg[ks] + 4 * n
+        ad = o(f"ad.{adname}[{n}]")
+        return [f"ds_read_b64_tr_b16 v[{lo}:{lo + 1}], {ad} offset:{buf * BUF + ks * 16384}",
+                f"ds_read_b64_tr_b16 v[{lo + 2}:{lo + 3}], {ad} offset:{buf * BUF + ks * 16384 + 2048}"]
+    ra = [frag(akc, FA_BASE, FA, "adA", i, 0) for i in range(8)]
+    rb = [frag(bkc, FB_BASE, FB, "adB", j, 1) for j in range(8)]
     return [ra[0]] + rb + ra[1:]
 
 
@@ -131,16 +133,18 @@ def variants(out, conds_texts):
         out.append(f"    {kw} asm volatile({txt} : : {ops} : {CLOB});")
 
 
+LAYOUTS = ((1, 1), (1, 0), (0, 0))
 SIG = "const W4Addr& ad, const u32x4& rA, const u32x4& rB, int koffA, int koffB"
-out = ["// GENERATED by scripts/gen_w4_dma.py -- do not edit (register plan and schedule: the generator's docstring).",
-       "// BKC = 1: B K-contiguous (nn.Linear forward); BKC = 0: B K-strided (dgrads, the [E, in, out] expert weights).",
+out = ["// GENERATED by scripts/gen_w4_acc.py -- do not edit (register plan and schedule: the generator's docstring).",
+       "// (AKC, BKC) = (1, 1): both operands K-contiguous (nn.Linear forward); (1, 0): B K-strided (dgrads, the [E, in, out] expert weights);",
+       "// (0, 0): both K-strided (weight gradients: contraction over the tokens).",
        ""]
 
 # ---- prologue: k-tile 0 -> buffer 0, k-tile 1 -> buffer 1; k-tile 0 landed
-out.append("template <int BKC>")
+out.append("template <int AKC, int BKC>")
 out.append(f"__device__ __forceinline__ void w4_prologue({SIG}, int koffA1, int koffB1) {{")
 cs = []
-for bkc in (1, 0):
+for akc, bkc in LAYOUTS[:1]:             # (the DMA loads do not depend on the layout: the offsets carry it)
     o = Ops()
     pro = []
     for x in range(16):
@@ -150,30 +154,31 @@ for bkc in (1, 0):
         d = dma(o, x, 1, "koffA1", "koffB1")
         pro += [d[0], "s_nop 0", d[1]]
     pro += ["s_waitcnt vmcnt(16)"]
-    cs.append((f"BKC == {bkc}", emit(pro), o.text()))
+    cs.append(("true", emit(pro), o.text()))
 variants(out, cs)
 out.append("}")
 out.append("// the barrier that publishes buffer 0, then the fragment reads of its k-step 0")
-out.append("template <int BKC>")
+out.append("template <int AKC, int BKC>")
 out.append("__device__ __forceinline__ void w4_first_reads(const W4Addr& ad) {")
 cs = []
-for bkc in (1, 0):
+for akc, bkc in LAYOUTS:
     o = Ops()
-    cs.append((f"BKC == {bkc}", emit(["s_barrier"] + reads(o, bkc, 0, 0)), o.text()))
+    cs.append((f"AKC == {akc} && BKC == {bkc}", emit(["s_barrier"] + reads(o, akc, bkc, 0, 0)), o.text()))
 variants(out, cs)
 out.append("}")
 out.append("")
 
 
 def gen(name, flagname, build):
-    out.append(f"template <int BKC, int BUFI, bool {flagname}>")
+    out.append(f"template <int AKC, int BKC, int BUFI, bool {flagname}>")
     out.append(f"__device__ __forceinline__ void {name}({SIG}) {{")
     cs = []
-    for bkc in (1, 0):
+    for akc, bkc in LAYOUTS:
         for b in range(2):
             for flag in (True, False):
                 o = Ops()
-                cs.append((f"BKC == {bkc} && BUFI == {b} && {flagname if flag else '!' + flagname}", emit(build(o, bkc, b, flag)), o.text()))
+                cs.append((f"AKC == {akc} && BKC == {bkc} && BUFI == {b} && {flagname if flag else '!' + flagname}",
+                           emit(build(o, akc, bkc, b, flag)), o.text()))
     variants(out, cs)
     out.append("}")
 
@@ -195,26 +200,26 @@ def stream(fresh):
     return mfmas(0, fresh) + mfmas(1, False)
 
 
-def p1(o, bkc, b, fresh):
-    return part(stream(fresh)[:CUT1], reads(o, bkc, 1, b), ["s_waitcnt lgkmcnt(0)"], ["s_waitcnt lgkmcnt(0)", "s_barrier"])
+def p1(o, akc, bkc, b, fresh):
+    return part(stream(fresh)[:CUT1], reads(o, akc, bkc, 1, b), ["s_waitcnt lgkmcnt(0)"], ["s_waitcnt lgkmcnt(0)", "s_barrier"])
 
 
-def p2(o, bkc, b, fresh):
+def p2(o, akc, bkc, b, fresh):
     fill = []
     for x in range(16):
         fill += dma(o, x, b)             # M0 write and its load in different MFMA gaps (the MFMA between them is the wait state)
     return part(stream(fresh)[CUT1:CUT2], fill, [], ([] if fresh else ["s_waitcnt vmcnt(16)"]) + ["s_barrier"])
 
 
-def p3(o, bkc, b, unused):
+def p3(o, akc, bkc, b, unused):
     mm = stream(False)[CUT2:]
-    return part(mm, reads(o, bkc, 0, b ^ 1), [], [], span=max(len(mm) - 6, 1))
+    return part(mm, reads(o, akc, bkc, 0, b ^ 1), [], [], span=max(len(mm) - 6, 1))
 
 
 gen("w4_h0", "FRESH", p1)
 gen("w4_h1", "FRESH", p2)
 gen("w4_h2", "NOWAIT", p3)
-out.append("template <int BKC, int BUFI>")
+out.append("template <int AKC, int BKC, int BUFI>")
 out.append("__device__ __forceinline__ void w4_h3(const W4Addr&) {}      // (the LDS-DMA schedule has three parts)")
 out.append("")
 out.append("// Accumulator blocks (I, 4 JH + q), q = 0..3, as fp32: r[4 q + e] = row 16 I + lane % 16, column 16 (4 JH + q) + 4 (lane / 16) + e of the wave tile.")

@@ -672,6 +672,45 @@ def test_gemm_grouped_problems(hip, ks):
     assert L.md_gemm_bf16(ctypes.byref(a), st) == -1
 
 
+@pytest.mark.parametrize("ks", [1, 2, 4])
+@pytest.mark.parametrize("variant", ["pp256", "w4", "auto"])
+def test_gemm_grouped_problems_whole_tiles(hip, variant, ks):
+    """The grouped weight-gradient launch on shapes of whole 256 x 256 tiles (what a DiT block's group is), forced through pp256 and
+    through the 4-wave kernel (round 6: both operands K-strided through transposing LDS reads, fp32 slices stored 16 bytes per lane),
+    and by the library's own choice (enough tiles: w4)."""
+    import ctypes
+    torch.manual_seed(17 + ks)
+    L, st = hip.lib(), hip.stream_ptr()
+    T = 2048
+    shapes = [(1024, 768), (768, 1024), (512, 256), (256, 2816)]
+    sizes = [m * n for m, n in shapes]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    span = sum(sizes)
+    dys = [bf(torch.randn(T, m, device=DEV)) for m, _ in shapes]
+    xs = [bf(torch.randn(T, n, device=DEV) / math.sqrt(T)) for _, n in shapes]
+    probs = (hip.GemmProblem * len(shapes))()
+    for i, (m, n) in enumerate(shapes):
+        probs[i] = hip.GemmProblem(dys[i].data_ptr(), xs[i].data_ptr(), m, n, m, n, offs[i])
+    ws = torch.full((ks, span), float("nan"), device=DEV)
+    chosen = ctypes.c_int32(-1)
+    a = hip.GemmArgs()
+    for k, v in dict(A=dys[0].data_ptr(), B=xs[0].data_ptr(), C=ws.data_ptr(), M=shapes[0][0], N=shapes[0][1], K=T, lda=shapes[0][0],
+                     ldb=shapes[0][1], ldc=shapes[0][1], sSplit=span, batch=1, ksplit=ks, a_kcontig=0, b_kcontig=0,
+                     mode=hip.EPI_STORE_F32, act=0, alpha=1.0, problems=ctypes.addressof(probs), n_problems=len(shapes),
+                     variant=hip.GEMM_VARIANT_NAMES[variant], chosen_variant=ctypes.addressof(chosen)).items():
+        setattr(a, k, v)
+    hip.check(L.md_gemm_bf16(ctypes.byref(a), st), "grouped gemm")
+    if variant != "auto":
+        assert chosen.value == hip.GEMM_VARIANT_NAMES[variant]
+    G = torch.full((span,), 0.25, device=DEV)
+    hip.check(L.md_splitk_reduce_flat(ws.data_ptr(), G.data_ptr(), span, span, ks, 1, st), "flat reduce")
+    torch.cuda.synchronize()
+    assert torch.isfinite(ws).all()
+    for i, (m, n) in enumerate(shapes):
+        ref = 0.25 + dys[i].float().t() @ xs[i].float()
+        close(G[offs[i]:offs[i] + m * n].view(m, n), ref, rel=2e-3, what=f"{variant}: grouped problem {i} {m}x{n}, ksplit {ks}")
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_adamw_clip(hip):
     """clip_grad_norm_ + torch.optim.AdamW (train.py:39-43,85-86) vs md_sumsq / md_sumsq_finish / md_adamw_step, with the
