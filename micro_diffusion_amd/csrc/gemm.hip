@@ -602,6 +602,16 @@ extern "C" int md_splitk_reduce_flat(const float* ws, float* out, int64_t n, int
     return 0;
 }
 
+// Under a CU hold (md_gemm_args.cu_limit: the data-parallel step while a collective is on the wire) w4 -- which has no split-K tail -- is
+// taken only when its whole tiles make nearly whole rounds of the cu_limit workgroups: filled share of all rounds >= 92 % (256 tiles on 248
+// workgroups would be two rounds, 52 %: those launches keep PP256 and its tail form).  On a free chip the >= 192-tile rule stands alone.
+static bool md_gemm_w4_fills(int64_t tiles, int cu_limit) {
+    if (!(cu_limit > 0 && cu_limit < 256)) return true;
+    if (tiles <= cu_limit) return false;
+    const int64_t rounds = (tiles + cu_limit - 1) / cu_limit;
+    return tiles * 100 >= rounds * cu_limit * 92;
+}
+
 extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if (!a_in) return MD_BAD_ARG;
     md_gemm_args a_copy = *a_in;                     // raster_group_n is filled in below
@@ -611,8 +621,12 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
         if (a->variant != MD_GEMM_AUTO && a->variant != MD_GEMM_PP256 && a->variant != MD_GEMM_W4) return MD_NOT_ELIGIBLE;
         if (a->variant == MD_GEMM_W4 && !md_gemm_w4_eligible(a)) return MD_NOT_ELIGIBLE;
         // the 4-wave kernel takes the grouped weight gradients it covers (whole interior tiles) on a free chip (profiles/r6_w4_wgrad.txt)
-        const bool w4 = a->variant == MD_GEMM_W4 || (a->variant == MD_GEMM_AUTO && md_gemm_w4_eligible(a) && !(a->cu_limit > 0 && a->cu_limit < 256) &&
-                                                     !getenv("MD_GEMM_NO_W4") && !getenv("MD_GEMM_NO_W4_TN"));
+        bool w4 = a->variant == MD_GEMM_W4;
+        if (a->variant == MD_GEMM_AUTO && md_gemm_w4_eligible(a) && !getenv("MD_GEMM_NO_W4") && !getenv("MD_GEMM_NO_W4_TN")) {
+            int64_t t = 0;
+            for (int i = 0; i < a->n_problems; ++i) t += ((a->problems[i].M + 255) / 256) * ((a->problems[i].N + 255) / 256);
+            w4 = md_gemm_w4_fills(t * a->ksplit, a->cu_limit);
+        }
         if (a->chosen_variant) *a->chosen_variant = w4 ? MD_GEMM_W4 : MD_GEMM_PP256;
         return w4 ? md_gemm_w4_launch(a, stream) : md_gemm_pp_launch(a, stream);
     }
@@ -656,11 +670,11 @@ extern "C" int md_gemm_bf16(const md_gemm_args* a_in, hipStream_t stream) {
     if ((a->A_list || a->B_list) && !(a->A_list && a->B_list && md_gemm_pp_eligible(a))) return MD_BAD_ARG;   // operand lists: PP256 only
     if (a->A_list) variant = MD_GEMM_PP256;
     if (variant == MD_GEMM_AUTO) {
-        // W4 (round 6): the 4-wave 16x16x32 kernel where it measured ahead of PP256 -- K-contiguous x K-contiguous launches with
-        // at least 192 tiles and no CU hold (profiles/r6_w4_vs_pp256.txt); the md_gemm_args.cu_limit launches of the
-        // data-parallel step keep PP256 and its split-K tail
+        // W4 (round 6): the 4-wave 16x16x32 kernel wherever it is built for the problem and the launch has at least 192 tiles that make
+        // (nearly) whole rounds of the workgroups it may use (md_gemm_w4_fills: w4 has no split-K tail -- under a CU hold, 256 tiles on 248
+        // workgroups would be two rounds; those launches keep PP256 and its tail)
         const char* w4min = getenv("MD_GEMM_W4_MIN_TILES");            // (A/B runs; default: the launches PP256 used to take)
-        if (md_gemm_w4_eligible(a) && tiles256 >= (w4min ? atoi(w4min) : 192) && !(a->cu_limit > 0 && a->cu_limit < 256) && !getenv("MD_GEMM_NO_W4") &&
+        if (md_gemm_w4_eligible(a) && tiles256 >= (w4min ? atoi(w4min) : 192) && md_gemm_w4_fills(tiles256, a->cu_limit) && !getenv("MD_GEMM_NO_W4") &&
             (a->a_kcontig || !getenv("MD_GEMM_NO_W4_TN")))
             variant = MD_GEMM_W4;
         else if (md_gemm_pp_eligible(a) && tiles256 >= 192)
