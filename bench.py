@@ -15,7 +15,7 @@ Extra keys of the line (the headline fields are unchanged by them):
   rank_of_8_step, n8_ceiling   ONE 256-image microbatch per step through the production sharded exchange on a one-rank RCCL communicator, 248 CUs
                  (the rank-of-8 step emulated on one GPU) and 8 x that / the headline;
   roofline       dominant kernel (the MFMA GEMM family): flop / per-launch HIP-event time, plus HBM traffic per launch from
-                 the committed rocprofv3 PMC passes (profiles/r5_gemm_traffic.json: counters need rocprofv3 around the process,
+                 the committed rocprofv3 PMC passes (profiles/r6_gemm_traffic.json: counters need rocprofv3 around the process,
                  so they are NOT measured by this run -- `traffic_measured_in_run` false; the file carries the source hash of
                  the library it was measured on and `traffic` is null when that differs from the running build);
   roofline_hbm   the bandwidth-bound kernel classes (attention, LayerNorm, QK-LayerNorm, SwiGLU, gate backward, split-K reduce):
@@ -408,7 +408,7 @@ def main():
         traffic, tinfo = gemm_traffic()
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                           "kernel": "md_gemm_bf16 family (gemm_bf16_pp_kernel + gemm_bf16_kernel + gemm_bf16_dma_kernel)",
+                           "kernel": "md_gemm_bf16 family (gemm_bf16_w4_kernel + gemm_bf16_pp_kernel + gemm_bf16_kernel + gemm_bf16_dma_kernel)",
                            "launches": n, "avg_launch_us": tot_ms * 1e3 / n, "gflop_per_launch": tot_fl / n / 1e9,
                            "gemm_time_share_of_step": (tot_ms / ms_per_step) if world == 1 else None,
                            "algorithmic_bytes_per_launch": tot_by / n,

@@ -379,7 +379,7 @@ class DiTEngine:
         """Address in the bf16 exchange buffer a weight gradient of this step is stored at, or None (not a one-microbatch step, the
         output is not a gradient accumulator, or the tensor is not dense).  A second gradient for the same tensor within one backward
         would have to be ADDED: no layer of the model does that; it raises instead of silently dropping the first."""
-        t = self.wgrad_bf16
+        t = getattr(self, "wgrad_bf16", None)      # (host-logic tests build the engine without __init__)
         if t is None or numel is None or not (t["g_lo"] <= out_ptr < t["g_hi"]):
             return None
         if out_ptr in t["written"]:
