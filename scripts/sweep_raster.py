@@ -8,9 +8,11 @@ import torch                                    # noqa: E402
 from micro_diffusion_amd import hip             # noqa: E402
 
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+VARIANT = hip.GEMM_VARIANT_NAMES[sys.argv[2]] if len(sys.argv) > 2 else hip.GEMM_PP256      # python scripts/sweep_raster.py 1024 w4
 f = mb // 256
 SH = [(16384 * f, 1024, 1024, 1, 1), (16384 * f, 1024, 1024, 1, 0), (19712 * f, 2048, 1024, 1, 1), (65536 * f, 768, 768, 1, 1), (65536 * f, 2304, 768, 1, 1),
-      (65536 * f, 768, 2304, 1, 0), (16384 * f, 3072, 1024, 1, 1), (16384 * f, 1024, 3072, 1, 0), (65536 * f, 4096, 768, 1, 1)]
+      (65536 * f, 768, 2304, 1, 0), (16384 * f, 3072, 1024, 1, 1), (16384 * f, 1024, 3072, 1, 0), (65536 * f, 4096, 768, 1, 1), (16384 * f, 5632, 1024, 1, 1),
+      (16384 * f, 2688, 1024, 1, 1)]
 dev = "cuda"
 print(f"# microbatch {mb}; columns: raster_group_n = 0 (library rule), 1, 2, 3, 4, 6, 8, 12, 16")
 for M, N, K, akc, bkc in SH:
@@ -23,7 +25,7 @@ for M, N, K, akc, bkc in SH:
             row.append("   -")
             continue
         def run():
-            hip.gemm(A, B, C, M, N, K, lda=K, ldb=K if bkc else N, ldc=N, a_kcontig=akc, b_kcontig=bkc, variant=hip.GEMM_PP256, raster_group_n=g)
+            hip.gemm(A, B, C, M, N, K, lda=K, ldb=K if bkc else N, ldc=N, a_kcontig=akc, b_kcontig=bkc, variant=VARIANT, raster_group_n=g)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
