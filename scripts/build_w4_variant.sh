@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build scratch_libs/lib_w4_<name>.so = the current library with gemm_w4.hip recompiled on a k-loop schedule generated with the given
-# experiment flags (scripts/gen_w4_acc.py).  Usage: scripts/build_w4_variant.sh <name> [flag ...] [-- -DX ...]
+# schedule flags (scripts/gen_w4_acc.py: c1=<n> c2=<n>).  Usage: scripts/build_w4_variant.sh <name> [flag ...] [-- -DX ...]
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
