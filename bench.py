@@ -27,6 +27,7 @@ Extra keys of the line (the headline fields are unchanged by them):
                  /root/reference does not travel to the GPU box), >= 3 timed steps, threads used and host cores stated.
 """
 import argparse
+import ctypes
 import gc
 import json
 import os
@@ -314,6 +315,12 @@ def main():
     if args.rank_probe:
         print(json.dumps({"rank_probe": rank, "world": world, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}), flush=True)
         return
+    # The JSON line must be the ONLY thing on this command's stdout.  RCCL printf()s a version banner when a communicator is made
+    # (the rank_of_8_step leg makes one at N = 1 too) and stdio holds it until exit, i.e. AFTER the line: file descriptor 1 is
+    # pointed at stderr for the run and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` (it spawns its ranks) or "
                          f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
@@ -491,7 +498,9 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,8 +35,9 @@ for step in "$@"; do
       else timeout -k 10 1500 python -m pytest "$f" -m gpu -q -x > "$log" 2>&1; fi
       tail -n 12 "$log" ;;
     bench)
-      timeout -k 10 900 python bench.py $arg > "$log" 2>&1
-      tail -n 1 "$log" > gpurun_out/${tag}_bench.json; cut -c1-400 gpurun_out/${tag}_bench.json ;;
+      # stdout alone (as the driver reads it): it must hold the JSON line and nothing else
+      timeout -k 10 900 python bench.py $arg > gpurun_out/${tag}_bench.json 2> "$log"
+      echo "stdout lines: $(wc -l < gpurun_out/${tag}_bench.json)"; cut -c1-400 gpurun_out/${tag}_bench.json ;;
     stats)
       flags=${arg:---steps 3 --warmup 1 --no-cpu-baseline --no-other-stages --no-profile}
       ( cd /tmp && timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$tag" -- \
