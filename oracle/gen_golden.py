@@ -369,6 +369,11 @@ if __name__ == "__main__":
         # 250 optimiser steps of the unmodified reference at XL/2 widths (~25 min on 6-8 host threads)
         gen_curve_xl2(steps=250, fname="xl2_curve_250.npz", threads=int(os.environ.get("GEN_THREADS", "8")))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xl2_curve_1k":
+        # north_star: "loss curve matching reference within 1 % over 1 k steps" at the benchmarked width (~100 min on 6 host threads);
+        # same recipe, batches 100 .. 1099: its first 250 losses must equal xl2_curve_250.npz's (checked by tests/test_oracle_golden.py)
+        gen_curve_xl2(steps=1000, fname="xl2_curve_1k.npz", threads=int(os.environ.get("GEN_THREADS", "8")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "curve_hot":
         gen_curve_hot()
         sys.exit(0)
