@@ -253,7 +253,7 @@ def gemm_traffic():
     """HBM bytes per GEMM launch of the headline step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate --pmc runs, calibrated on a 1 GiB copy of the same pass; scripts/pmc_workload.py + scripts/pmc_traffic.py write the
     file).  The counters need rocprofv3 around the process, so they are NOT measured by this run; the number is returned only
-    when the file was measured on THIS build of the library (source hash stamped into it), else null + `stale`."""
+    when the file was measured on THIS build of the GEMM kernels (hash of the GEMM sources stamped into it), else null + `stale`."""
     from micro_diffusion_amd import hip
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
@@ -261,8 +261,13 @@ def gemm_traffic():
     with open(path) as fh:
         t = json.load(fh)
     info = {k: v for k, v in t.items() if k != "per_kernel"}
+    # keyed to the GEMM sources (gemm*.hip + headers + flags); files written before that key existed carry the whole-library hash
+    if "gemm_source_hash" in t:
+        stale = t["gemm_source_hash"] != hip._gemm_source_hash()
+    else:
+        stale = t.get("library_source_hash") != hip._source_hash()
     info.update(file="profiles/" + TRAFFIC_FILE, traffic_measured_in_run=False, running_build=hip._source_hash(),
-                stale=t.get("library_source_hash") != hip._source_hash())
+                running_gemm_sources=hip._gemm_source_hash(), stale=stale)
     return (None if info["stale"] else t.get("bytes_per_launch")), info
 
 

@@ -35,6 +35,21 @@ def _sources():
     return sorted(f for f in os.listdir(_CSRC) if f.endswith(".hip"))
 
 
+def _gemm_source_hash() -> str:
+    """Hash of what determines the GEMM kernels alone (gemm*.hip, their headers and generated includes, md_common.h, the public header,
+    the compiler flags): the key of profiles/*_gemm_traffic.json, so that an edit of attention.hip does not void a GEMM measurement."""
+    h = hashlib.sha256()
+    files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))
+             if f.endswith((".hip", ".h", ".inc")) and (f.startswith("gemm") or f == "md_common.h")]
+    files.append(os.path.join(_INCLUDE, "microdit_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def _source_hash() -> str:
     h = hashlib.sha256()
     files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h"))]

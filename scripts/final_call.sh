@@ -3,7 +3,9 @@
 #   gpurun --timeout 2400 -- 'bash scripts/final_call.sh <tag>'
 cd "$GRAFT_REPO_ROOT" || exit 1
 t=${1:-m1}
-bash scripts/gpu_call.sh $t tests "bench" "stats:--steps+3+--warmup+1+--no-cpu-baseline+--no-other-stages+--no-profile" traffic
+bash scripts/gpu_call.sh $t traffic
+cp gpurun_out/${t}_gemm_traffic.json profiles/r6_gemm_traffic.json     # on the box: the bench below reads roofline.traffic from it (keyed to the GEMM sources)
+bash scripts/gpu_call.sh $t tests "bench" "stats:--steps+3+--warmup+1+--no-cpu-baseline+--no-other-stages+--no-profile"
 cp gpurun_out/${t}_kernel_stats.txt gpurun_out/${t}_kernel_stats_mb1024.txt
 bash scripts/gpu_call.sh ${t}b "stats:--microbatch+256+--steps+2+--warmup+1+--no-cpu-baseline+--no-other-stages+--no-profile" dp2gloo
 cp gpurun_out/${t}b_kernel_stats.txt gpurun_out/${t}_kernel_stats_mb256.txt

@@ -49,7 +49,7 @@ def main():
     wb = sum(sum(v) for v in gem_w.values()) * w_cal
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from micro_diffusion_amd import hip
-    res = {"library_source_hash": hip._source_hash(), "bytes_per_launch": (fb + wb) / n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "launches": n,
+    res = {"library_source_hash": hip._source_hash(), "gemm_source_hash": hip._gemm_source_hash(), "bytes_per_launch": (fb + wb) / n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "launches": n,
            "calibration": {"fetch_counter_to_bytes": f_cal, "write_counter_to_bytes": w_cal, "on": fk[:60],
                            "note": "factor that maps the counter to 2^30 bytes on a torch copy of 1 GiB in the same run"},
            "per_kernel": {k[:70]: {"launches": len(v), "fetch_bytes_per_launch": sum(v) * f_cal / len(v),
