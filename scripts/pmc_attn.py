@@ -1,5 +1,6 @@
-"""Attention launches for rocprofv3 --pmc passes: python scripts/pmc_attn.py [B]  (S = 1024 / 1024 x 77 / 256 self-attention, forward +
-the library's backward, 3 launches each; kernels are told apart by name in the counter CSV)."""
+"""Attention launches for rocprofv3 --pmc passes: python scripts/pmc_attn.py [B] [small]  (S = 1024 / 1024 x 77 / 256 self-attention, forward +
+the library's backward, 3 launches each; kernels are told apart by name in the counter CSV).  "small": the backbone's 64-row shapes
+instead (64 x 64 self-attention and 64 x 77 cross-attention, 16 heads, 4 B samples)."""
 import math
 import os
 import sys
@@ -11,7 +12,10 @@ from micro_diffusion_amd import hip             # noqa: E402
 
 L, dev = hip.lib(), "cuda"
 BB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for B, H, Sq, Skv, packed in ((BB, 12, 1024, 1024, True), (BB, 12, 1024, 77, False), (BB * 4, 12, 256, 256, True)):
+SHAPES = ((BB, 12, 1024, 1024, True), (BB, 12, 1024, 77, False), (BB * 4, 12, 256, 256, True))
+if len(sys.argv) > 2 and sys.argv[2] == "small":
+    SHAPES = ((BB * 4, 16, 64, 64, True), (BB * 4, 16, 64, 77, False))
+for B, H, Sq, Skv, packed in SHAPES:
     hd, hid = 64, H * 64
     if packed:
         qkv = torch.randn(B, Sq, 3 * hid, device=dev).bfloat16(); dqkv = torch.zeros_like(qkv)
