@@ -167,14 +167,19 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
 // Store a transposed accumulator tile: acc[di] holds X^T[d][row] with lane <-> row, regs <-> d.
 // Workgroup -> (batch, head).  The dispatcher deals consecutive workgroups to the 8 XCDs in turn, so with (b, h) = the plain grid index
 // an XCD gets every 8th head: a 128-byte slice of every row of every sample, its neighbours' slices going through seven other L2s.
-// Here XCD x walks the x-th CONTIGUOUS eighth of the (batch, head) pairs instead (workgroup 8 s + x -> x n/8 + s; the n mod 8 last
-// ones keep their index), all heads of a sample side by side.  Measured on the 64-row shapes (1024 x 16 heads, call x1, A B A B):
-// forward 138 -> 124 us, 64 x 77 forward 147 -> 136, backward 369 -> 349, caption 77 x 77 backward 419 -> 401; 256-row and longer
-// shapes +-1 %.  (The same remap on the row-contiguous LayerNorm kernels LOSES 9-14 %, and a variant in which the XCDs share a window of
-// 8 samples, one sample each, gains 3 % more on the forwards but loses 16 % on the 77-key backwards: profiles/r6_notes.txt section 8.)
+// Here the XCDs share a window of 8 consecutive samples and each takes ONE WHOLE sample of it, its heads in consecutive slots
+// (workgroup 8 s + x -> sample 8 (s / H) + x, head s mod H; the B mod 8 last samples keep the plain order).  Same bytes and the same
+// L2 hit rate as before; 40 % fewer read-credit and tag stalls at the L2 channels (profiles/r6_attention_xcd_pmc.txt).  Measured on
+// the 64-row shapes (1024 x 16 heads, A B A B on one box, us plain -> this): 64 x 64 forward 138 -> 120, backward 315 -> 298; 64 x 77
+// forward 147 -> 130, backward 372 -> 343; 77 x 77 forward 176 -> 168, backward 418 -> 394; 256-row shapes +-1 %.  The group size was
+// swept (1 ... B H / 8 pairs per XCD turn: flat optimum at 8-32 pairs, "contiguous eighths" 3 % behind); the same idea LOSES 9-14 % on the
+// row-contiguous LayerNorm kernels (profiles/r6_notes.txt section 8).
 __device__ __forceinline__ void bh_of(int64_t lin, int64_t H, int64_t B, int64_t& b, int64_t& h) {
-    const int64_t per = (H * B) >> 3;
-    if (lin < (per << 3)) lin = (lin & 7) * per + (lin >> 3);
+    const int64_t n8 = (B >> 3) * 8 * H;                // whole windows of 8 samples
+    if (lin < n8) {
+        const int64_t s = lin >> 3, x = lin & 7;        // slot s of XCD x
+        lin = ((s / H) * 8 + x) * H + s % H;
+    }
     b = lin / H;
     h = lin - b * H;
 }
