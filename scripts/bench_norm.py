@@ -13,6 +13,7 @@ from micro_diffusion_amd import hip  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--mb", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--rpb-sweep", action="store_true", help="md_ln_bwd with rows_per_block 8 .. rows per sample (the engine's rule: DiTEngine._rows_per_block)")
 args = ap.parse_args()
 L, st, dev = hip.lib(), hip.stream_ptr(), "cuda"
 
@@ -43,12 +44,18 @@ for name, rows, C, rps in (("backbone", args.mb * 64, 1024, 64), ("mixer", args.
     a = hip.LnArgs(x.data_ptr(), w.data_ptr(), mod.data_ptr(), mod[:, C:].data_ptr(), None, out.data_ptr(), mean.data_ptr(),
                    rstd.data_ptr(), rows, C, C, C, 6 * C, rps, 0, 1e-6, 0)
     rpb = 64
-    while rpb > 4 and (rows + rpb - 1) // rpb < 2048:
+    while rpb > 4 and (rows + rpb - 1) // rpb < 1024:     # DiTEngine._rows_per_block(rows, rps, 1024)
         rpb //= 2
     b = hip.LnBwdArgs(dz.data_ptr(), dx.data_ptr(), dmod[:, C:].data_ptr(), dmod.data_ptr(), dw.data_ptr(), C, C, 6 * C,
                       min(rpb, rps), 0, 1)
     timed(lambda: hip.check(L.md_ln_fwd(byref(a), st), "ln"), rows * C * 4, f"{name} ln_fwd   [{rows} x {C}]")
     timed(lambda: hip.check(L.md_ln_bwd(byref(a), byref(b), st), "lnb"), rows * C * 6, f"{name} ln_bwd   [{rows} x {C}]")
+    if args.rpb_sweep:
+        r = 8
+        while r <= rps:
+            b2 = hip.LnBwdArgs(dz.data_ptr(), dx.data_ptr(), dmod[:, C:].data_ptr(), dmod.data_ptr(), dw.data_ptr(), C, C, 6 * C, r, 0, 1)
+            timed(lambda: hip.check(L.md_ln_bwd(byref(a), byref(b2), st), "lnb"), rows * C * 6, f"{name} ln_bwd   rows_per_block {r} ({rows // r} workgroups)")
+            r *= 2
     qkv = (torch.randn(rows, 3 * C, device=dev)).to(torch.bfloat16)
     dqkv = torch.randn(rows, 3 * C, device=dev).to(torch.bfloat16)
     rq = torch.empty(rows, device=dev)
